@@ -1,0 +1,84 @@
+"""ctypes binding of ``libgsage.so`` (the HIP kernels + C ABI in ``csrc/``).
+
+There is no fallback: if the library is missing or a call fails, an exception
+is raised.  ``torch`` is imported before the library is opened so that both use
+the one HIP runtime torch has already loaded (same SONAME), which is what makes
+torch's device pointers and stream handles valid inside the library.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgsage.so')
+
+GS_OK = 0
+GS_MAX_HOPS = 4
+ACT = {'linear': 0, 'relu': 1}
+
+_c = ctypes
+_vp, _i32, _i64, _u64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/gsage.h declaration by declaration
+SIGNATURES = {
+    'gs_version': (_i32, []),
+    'gs_last_error': (_c.c_char_p, []),
+    'gs_sample': (_i32, [_vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32), _i32, _u64, _u64, _vp, _vp,
+                         _c.POINTER(_vp), _vp, _vp]),
+    'gs_gather_rows': (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp]),
+    'gs_gather_mean_fwd': (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
+    'gs_gather_mean_bwd': (_i32, [_vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _vp]),
+    'gs_sage_project_fwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'gs_sage_project_bwd_workspace': (_sz, [_i32, _i32, _i32, _i64]),
+    'gs_sage_project_bwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'gs_l2_normalize_fwd': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'gs_l2_normalize_bwd': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class GsageError(RuntimeError):
+    pass
+
+
+def load():
+    """Opens libgsage.so (once) and declares every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GsageError(
+            "libgsage.so is not built (%s missing): run `make -C graphsage_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback" % LIB_PATH)
+    import torch  # noqa: F401  (loads the HIP runtime the library must share)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != GS_OK:
+        msg = load().gs_last_error()
+        raise GsageError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ''))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise GsageError("no MI355X visible: the GraphSAGE hot path runs only as HIP kernels on the GPU")
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,51 @@
+// Shared host/device helpers of libgsage.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "gsage.h"
+
+namespace gs {
+
+// Thread-local error text returned by gs_last_error().
+char *error_buffer();
+int fail(int code, const char *fmt, ...);
+
+// Checks the launch that was just made on this thread.
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return GS_OK;
+}
+
+constexpr int kWave = 64;
+
+__host__ __device__ inline int ilog2_ceil(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), first output word only.
+__device__ __forceinline__ uint32_t philox4x32_10_x(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                    uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += W0;
+        k1 += W1;
+    }
+    return c0;
+}
+
+}  // namespace gs

@@ -1,0 +1,437 @@
+// Kernel 3: per-node-type self/neighbor projection on the fp32 matrix cores
+// (forward and backward), plus the l2 normalisation of the final embeddings.
+//
+//   out[m, 0:H/2]  = x_self[m, :] @ W_self        out[m, H/2:H] = x_mean[m, :] @ W_neigh
+//   out = act(out + bias)
+//
+// rows_gemm_kernel is a row-streaming GEMM  out[M, N] = A[M, K] @ B[K, N]  for
+// two independent "sides" in one launch (blockIdx.y picks the side and a
+// 64-column block inside it, blockIdx.x a 64-row block).  Forward: the sides are
+// the self and the neighbor half.  Backward w.r.t. the inputs: A is the masked
+// output gradient of one half and B the transposed weight, selected by strides.
+// A block is 4 waves, wave w owning rows 16w..16w+15 of the tile and up to four
+// 16x16 accumulators (v_mfma_f32_16x16x4_f32: A[row = lane&15][k = lane>>4],
+// B[k = lane>>4][col = lane&15], D[row = 4*(lane>>4) + i][col = lane&15]).
+// K is walked in steps of 32 through LDS; out-of-range rows/columns/k are
+// zero-filled while staging, so every shape is handled by the same code.
+//
+// wgrad_kernel forms the weight and bias gradients  dW[K, N] = A[M, K]^T @ G[M, N]
+// with the sum over M split into chunks: each block writes the partial sum of
+// its chunk to a slab, wgrad_reduce_kernel adds the slabs in chunk order, so
+// the result is bitwise reproducible (no float atomics).  The bias gradient is
+// the extra row K of the same product (A extended by a column of ones).
+//
+// LDS images are padded so fragment reads are conflict-free for ds_read_b32
+// (bank = dword address mod 32 inside each 32-lane half): tiles read with the
+// row on the lane use a row stride of 34 dwords (rows 0..15 land on even banks,
+// k and k+1 fill the odd ones), tiles read with the column on the lane a row
+// stride of 80 (k and k+1 are 16 banks apart).
+#include "gs_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int A_LD = 34, W_LD = 80;
+constexpr int kThreads = 256;
+
+struct GemmSide {
+    const float *A;      // [M, K], row stride lda
+    const float *mask;   // same indexing as A; element used only where mask > 0 (NULL: no mask)
+    const float *B;      // B(k, n) = B[k*ldbk + n*ldbn]
+    const float *bias;   // [N] or NULL
+    float *out;          // [M, N], row stride ldo
+    int lda, K, N, ldbk, ldbn, ldo;
+    int vec;             // 16-byte loads of A rows are legal
+    int ncb;             // 64-column blocks of this side
+};
+
+__global__ __launch_bounds__(kThreads)
+void rows_gemm_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
+    __shared__ float As[BM * A_LD];
+    __shared__ float Ws[BK * W_LD];
+    // pick this block's side field by field (a runtime-selected struct copy would live in scratch)
+    const bool second = (int)blockIdx.y >= s0.ncb;
+#define GS_SEL(f) (second ? s1.f : s0.f)
+    const int col0 = ((int)blockIdx.y - (second ? s0.ncb : 0)) * BN;
+    const float *__restrict__ A = GS_SEL(A);
+    const float *__restrict__ Mk = GS_SEL(mask);
+    const float *__restrict__ B = GS_SEL(B);
+    const float *__restrict__ bias = GS_SEL(bias);
+    float *__restrict__ outp = GS_SEL(out);
+    const int K = GS_SEL(K), N = GS_SEL(N), lda = GS_SEL(lda);
+    const int ldbk = GS_SEL(ldbk), ldbn = GS_SEL(ldbn), ldo = GS_SEL(ldo), vec = GS_SEL(vec);
+#undef GS_SEL
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, kk = lane >> 4;
+    const int ncols = min(BN, N - col0);
+    const int nt = (ncols + 15) >> 4;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        // stage the 64 x 32 slice of A: 8 lanes cover one row's 128 bytes
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = pass * 32 + (tid >> 3);
+            const int kq = (tid & 7) * 4;
+            const int64_t grow = row0 + row;
+            const int k = k0 + kq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (grow < M) {
+                const float *src = A + grow * lda + k;
+                if (vec && k + 3 < K) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    if (Mk) {
+                        const float4 m = *reinterpret_cast<const float4 *>(Mk + grow * lda + k);
+                        if (!(m.x > 0.f)) v[0] = 0.f;
+                        if (!(m.y > 0.f)) v[1] = 0.f;
+                        if (!(m.z > 0.f)) v[2] = 0.f;
+                        if (!(m.w > 0.f)) v[3] = 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (k + i < K) {
+                            v[i] = src[i];
+                            if (Mk && !(Mk[grow * lda + k + i] > 0.f)) v[i] = 0.f;
+                        }
+                    }
+                }
+            }
+            float *dst = As + row * A_LD + kq;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        }
+        // stage the 32 x 64 slice of B
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int wk = pass * 16 + (tid >> 4);
+            const int c4 = (tid & 15) * 4;
+            const int k = k0 + wk;
+            float *dst = Ws + wk * W_LD + c4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = col0 + c4 + i;
+                dst[i] = (k < K && col < N) ? B[(int64_t)k * ldbk + (int64_t)col * ldbn] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            const float a = As[(wave * 16 + r) * A_LD + ks * 4 + kk];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (ct < nt) {
+                    const float b = Ws[(ks * 4 + kk) * W_LD + ct * 16 + r];
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[ct], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        if (ct < nt) {
+            const int col = col0 + ct * 16 + r;
+            if (col < N) {
+                const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t grow = row0 + wave * 16 + kk * 4 + i;
+                    if (grow < M) {
+                        float v = acc[ct][i] + bv;
+                        if (act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                        outp[grow * ldo + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- weight / bias gradient ------------------------------------------------
+
+struct WgradSide {
+    const float *X;      // [M, K] row stride K (the forward input of this half)
+    const float *G;      // output gradient of this half, row stride ldg
+    const float *mask;   // forward output of this half (relu mask) or NULL, row stride ldg
+    float *slab;         // [n_chunks][K + 1][N] partial sums
+    int K, N, ldg;
+    int nkb, ncb;        // 64-row blocks over K+1, 64-column blocks over N
+};
+
+constexpr int WG_ROWS = 32;            // rows of M staged per step
+
+__global__ __launch_bounds__(kThreads)
+void wgrad_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk) {
+    __shared__ float Xs[WG_ROWS * W_LD];
+    __shared__ float Gs[WG_ROWS * W_LD];
+    const int tiles0 = s0.nkb * s0.ncb;
+    const bool second = (int)blockIdx.y >= tiles0;
+#define GS_SEL(f) (second ? s1.f : s0.f)
+    const float *__restrict__ X = GS_SEL(X);
+    const float *__restrict__ G = GS_SEL(G);
+    const float *__restrict__ Mk = GS_SEL(mask);
+    float *__restrict__ slab_base = GS_SEL(slab);
+    const int K = GS_SEL(K), N = GS_SEL(N), ldg = GS_SEL(ldg), ncb = GS_SEL(ncb);
+#undef GS_SEL
+    const int tile = (int)blockIdx.y - (second ? tiles0 : 0);
+    const int kb0 = (tile / ncb) * 64;            // first row of dW (k index) of this block
+    const int col0 = (tile % ncb) * 64;
+    const int64_t chunk = blockIdx.x;
+    const int64_t m_begin = chunk * rows_per_chunk;
+    const int64_t m_end = min(M, m_begin + rows_per_chunk);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int nt = (min(64, N - col0) + 15) >> 4;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_ROWS) {
+        // 32 rows x 64 columns of X (column K is the constant 1 that yields the bias row)
+        // and of the masked gradient; 16 lanes cover one row
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = pass * 16 + (tid >> 4);
+            const int c4 = (tid & 15) * 4;
+            const int64_t m = m0 + row;
+            const bool live = m < m_end;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kb0 + c4 + i;
+                float xv = 0.f;
+                if (live) xv = k < K ? X[m * K + k] : (k == K ? 1.f : 0.f);
+                Xs[row * W_LD + c4 + i] = xv;
+                const int c = col0 + c4 + i;
+                float gv = 0.f;
+                if (live && c < N) {
+                    gv = G[m * ldg + c];
+                    if (Mk && !(Mk[m * ldg + c] > 0.f)) gv = 0.f;
+                }
+                Gs[row * W_LD + c4 + i] = gv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ms = 0; ms < WG_ROWS / 4; ++ms) {
+            const float a = Xs[(ms * 4 + q) * W_LD + wave * 16 + r];        // A[k][m] = X[m][k]
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (ct < nt) {
+                    const float b = Gs[(ms * 4 + q) * W_LD + ct * 16 + r];
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[ct], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    float *slab = slab_base + chunk * (int64_t)(K + 1) * N;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        if (ct < nt) {
+            const int col = col0 + ct * 16 + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kb0 + wave * 16 + q * 4 + i;
+                if (k <= K && col < N) slab[(int64_t)k * N + col] = acc[ct][i];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads)
+void wgrad_reduce_kernel(const float *__restrict__ slab, int n_chunks, int K, int N,
+                         float *__restrict__ gW, float *__restrict__ gbias) {
+    const int total = (K + 1) * N;
+    for (int e = blockIdx.x * kThreads + threadIdx.x; e < total; e += gridDim.x * kThreads) {
+        float s = 0.f;
+        for (int c = 0; c < n_chunks; ++c) s += slab[(int64_t)c * total + e];
+        if (e < K * N) { if (gW) gW[e] = s; }
+        else if (gbias) gbias[e - K * N] = s;
+    }
+}
+
+// ---- l2 normalisation ---------------------------------------------------------
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One wave per row: sum of squares by lane-strided loads + xor-shuffle tree.
+__global__ __launch_bounds__(kThreads)
+void l2norm_fwd_kernel(const float *__restrict__ x, int64_t M, int H, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
+    for (int64_t m = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); m < M; m += stride) {
+        float ss = 0.f;
+        for (int c = lane; c < H; c += 64) { const float v = x[m * H + c]; ss += v * v; }
+        ss = wave_sum(ss);
+        const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+        for (int c = lane; c < H; c += 64) out[m * H + c] = x[m * H + c] * inv;
+    }
+}
+
+// y = x * s, s = rsqrt(max(ss, eps)):  g_x = s * g - [ss > eps] * s^3 * <g, x> * x
+__global__ __launch_bounds__(kThreads)
+void l2norm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g, int64_t M, int H,
+                       float *__restrict__ gx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
+    for (int64_t m = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); m < M; m += stride) {
+        float ss = 0.f, dot = 0.f;
+        for (int c = lane; c < H; c += 64) {
+            const float v = x[m * H + c];
+            ss += v * v;
+            dot += v * g[m * H + c];
+        }
+        ss = wave_sum(ss);
+        dot = wave_sum(dot);
+        const float s = rsqrtf(fmaxf(ss, 1e-12f));
+        const float k = ss > 1e-12f ? s * s * s * dot : 0.f;
+        for (int c = lane; c < H; c += 64) gx[m * H + c] = s * g[m * H + c] - k * x[m * H + c];
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline int check_project_shape(const char *who, int Fs, int Fn, int64_t M, int H, int act) {
+    if (H < 2 || (H & 1)) return gs::fail(GS_EINVAL, "%s: H=%d must be a positive multiple of two", who, H);
+    if (Fs < 1 || Fn < 1 || M < 0) return gs::fail(GS_EINVAL, "%s: Fs=%d Fn=%d M=%lld", who, Fs, Fn, (long long)M);
+    if (act != GS_ACT_LINEAR && act != GS_ACT_RELU) return gs::fail(GS_EINVAL, "%s: unknown activation %d", who, act);
+    return GS_OK;
+}
+
+// chunks of the M dimension for the weight-gradient partial sums
+inline void wgrad_chunks(int64_t M, int64_t *rows_per_chunk, int64_t *n_chunks) {
+    int64_t rpc = 512;
+    while ((M + rpc - 1) / rpc > 1024) rpc *= 2;
+    *rows_per_chunk = rpc;
+    *n_chunks = M > 0 ? (M + rpc - 1) / rpc : 0;
+}
+
+}  // namespace
+
+extern "C" int gs_sage_project_fwd(const float *x_self, int Fs, const float *x_mean, int Fn, int64_t M,
+                                   const float *W_self, const float *W_neigh, const float *bias,
+                                   int H, int act, float *out, void *stream) {
+    if (!x_self || !x_mean || !W_self || !W_neigh || !out)
+        return gs::fail(GS_EINVAL, "gs_sage_project_fwd: null pointer argument");
+    if (int rc = check_project_shape("gs_sage_project_fwd", Fs, Fn, M, H, act)) return rc;
+    if (M == 0) return GS_OK;
+    const int Hh = H / 2;
+    GemmSide s0{}, s1{};
+    s0.A = x_self; s0.B = W_self; s0.bias = bias; s0.out = out;
+    s0.lda = Fs; s0.K = Fs; s0.N = Hh; s0.ldbk = Hh; s0.ldbn = 1; s0.ldo = H;
+    s0.vec = Fs % 4 == 0 && aligned16(x_self); s0.ncb = (Hh + BN - 1) / BN;
+    s1.A = x_mean; s1.B = W_neigh; s1.bias = bias ? bias + Hh : nullptr; s1.out = out + Hh;
+    s1.lda = Fn; s1.K = Fn; s1.N = Hh; s1.ldbk = Hh; s1.ldbn = 1; s1.ldo = H;
+    s1.vec = Fn % 4 == 0 && aligned16(x_mean); s1.ncb = s0.ncb;
+    const int64_t bx = (M + BM - 1) / BM;
+    const int by = s0.ncb + s1.ncb;
+    if (bx > 0x7FFFFFFFLL || by > 65535) return gs::fail(GS_ELIMIT, "gs_sage_project_fwd: grid %lld x %d too large", (long long)bx, by);
+    hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)bx, (unsigned)by), dim3(kThreads), 0, (hipStream_t)stream,
+                       s0, s1, M, act);
+    return gs::check_launch("gs_sage_project_fwd");
+}
+
+extern "C" size_t gs_sage_project_bwd_workspace(int Fs, int Fn, int H, int64_t M) {
+    if (Fs < 1 || Fn < 1 || H < 2 || M < 0) return 0;
+    int64_t rpc, nc;
+    wgrad_chunks(M, &rpc, &nc);
+    return (size_t)nc * (size_t)(Fs + 1 + Fn + 1) * (size_t)(H / 2) * sizeof(float);
+}
+
+extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_mean, int Fn, int64_t M,
+                                   const float *W_self, const float *W_neigh, int H, int act,
+                                   const float *out, const float *g_out,
+                                   float *g_W_self, float *g_W_neigh, float *g_bias,
+                                   float *g_x_self, float *g_x_mean,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x_self || !x_mean || !W_self || !W_neigh || !g_out)
+        return gs::fail(GS_EINVAL, "gs_sage_project_bwd: null pointer argument");
+    if (int rc = check_project_shape("gs_sage_project_bwd", Fs, Fn, M, H, act)) return rc;
+    if (act == GS_ACT_RELU && !out) return gs::fail(GS_EINVAL, "gs_sage_project_bwd: relu needs the forward output");
+    const int Hh = H / 2;
+    hipStream_t s = (hipStream_t)stream;
+    const float *mask = act == GS_ACT_RELU ? out : nullptr;
+    const bool want_w = g_W_self || g_W_neigh || g_bias;
+
+    if (want_w) {
+        int64_t rpc, nc;
+        wgrad_chunks(M, &rpc, &nc);
+        const size_t need = gs_sage_project_bwd_workspace(Fs, Fn, H, M);
+        if (M > 0 && (!workspace || workspace_bytes < need))
+            return gs::fail(GS_EINVAL, "gs_sage_project_bwd: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+        float *slab0 = static_cast<float *>(workspace);
+        float *slab1 = slab0 + (size_t)nc * (Fs + 1) * Hh;
+        if (M > 0) {
+            WgradSide a{}, b{};
+            a.X = x_self; a.G = g_out; a.mask = mask; a.slab = slab0; a.K = Fs; a.N = Hh; a.ldg = H;
+            a.nkb = (Fs + 1 + 63) / 64; a.ncb = (Hh + 63) / 64;
+            b.X = x_mean; b.G = g_out + Hh; b.mask = mask ? mask + Hh : nullptr; b.slab = slab1; b.K = Fn; b.N = Hh; b.ldg = H;
+            b.nkb = (Fn + 1 + 63) / 64; b.ncb = a.ncb;
+            const int by = a.nkb * a.ncb + b.nkb * b.ncb;
+            if (by > 65535) return gs::fail(GS_ELIMIT, "gs_sage_project_bwd: %d weight tiles exceed the grid limit", by);
+            hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nc, (unsigned)by), dim3(kThreads), 0, s, a, b, M, rpc);
+            if (int rc = gs::check_launch("gs_sage_project_bwd (wgrad)")) return rc;
+        }
+        // bias gradient: row Fs of the self slab holds columns 0..Hh-1, row Fn of the neighbor slab Hh..H-1
+        const int tot0 = (Fs + 1) * Hh, tot1 = (Fn + 1) * Hh;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot0 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           slab0, (int)nc, Fs, Hh, g_W_self, g_bias);
+        if (int rc = gs::check_launch("gs_sage_project_bwd (reduce self)")) return rc;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           slab1, (int)nc, Fn, Hh, g_W_neigh, g_bias ? g_bias + Hh : nullptr);
+        if (int rc = gs::check_launch("gs_sage_project_bwd (reduce neigh)")) return rc;
+    }
+
+    if ((g_x_self || g_x_mean) && M > 0) {
+        GemmSide s0{}, s1{};
+        s0.A = g_out; s0.mask = mask; s0.B = W_self; s0.out = g_x_self;
+        s0.lda = H; s0.K = Hh; s0.N = g_x_self ? Fs : 0; s0.ldbk = 1; s0.ldbn = Hh; s0.ldo = Fs;
+        s0.vec = H % 4 == 0 && Hh % 4 == 0 && aligned16(g_out) && (!mask || aligned16(mask));
+        s0.ncb = (s0.N + BN - 1) / BN;
+        s1.A = g_out + Hh; s1.mask = mask ? mask + Hh : nullptr; s1.B = W_neigh; s1.out = g_x_mean;
+        s1.lda = H; s1.K = Hh; s1.N = g_x_mean ? Fn : 0; s1.ldbk = 1; s1.ldbn = Hh; s1.ldo = Fn;
+        s1.vec = s0.vec; s1.ncb = (s1.N + BN - 1) / BN;
+        const int64_t bx = (M + BM - 1) / BM;
+        const int by = s0.ncb + s1.ncb;
+        if (bx > 0x7FFFFFFFLL || by > 65535) return gs::fail(GS_ELIMIT, "gs_sage_project_bwd: grid %lld x %d too large", (long long)bx, by);
+        hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)bx, (unsigned)by), dim3(kThreads), 0, s, s0, s1, M, GS_ACT_LINEAR);
+        if (int rc = gs::check_launch("gs_sage_project_bwd (dx)")) return rc;
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_l2_normalize_fwd(const float *x, int64_t M, int H, float *out, void *stream) {
+    if (!x || !out) return gs::fail(GS_EINVAL, "gs_l2_normalize_fwd: null pointer argument");
+    if (H < 1 || M < 0) return gs::fail(GS_EINVAL, "gs_l2_normalize_fwd: M=%lld H=%d", (long long)M, H);
+    if (M == 0) return GS_OK;
+    int64_t blocks = (M + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, x, M, H, out);
+    return gs::check_launch("gs_l2_normalize_fwd");
+}
+
+extern "C" int gs_l2_normalize_bwd(const float *x, const float *g_out, int64_t M, int H, float *g_x, void *stream) {
+    if (!x || !g_out || !g_x) return gs::fail(GS_EINVAL, "gs_l2_normalize_bwd: null pointer argument");
+    if (H < 1 || M < 0) return gs::fail(GS_EINVAL, "gs_l2_normalize_bwd: M=%lld H=%d", (long long)M, H);
+    if (M == 0) return GS_OK;
+    int64_t blocks = (M + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, x, g_out, M, H, g_x);
+    return gs::check_launch("gs_l2_normalize_bwd");
+}

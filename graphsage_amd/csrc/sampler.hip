@@ -1,0 +1,129 @@
+// Kernel 1: CSR multi-hop uniform neighbor sampler, one wavefront per walk.
+//
+// A walk's hop h has size[h] = fanouts[0]*...*fanouts[h] slots; slot t of hop h
+// samples a neighbor of slot t / fanouts[h] of hop h-1 (the root for h = 0),
+// which is the order a FIFO breadth-first walk visits them.  The 64 lanes of the
+// wave take slots t = lane, lane+64, ...; the ids of a finished hop stay in the
+// wave's own LDS region so the next hop can look its parents up without going
+// back to memory.  Everything a slot needs (CSR row bounds, one random word, one
+// neighbor id) is independent of the other slots, so the kernel is a chain of
+// n_hops dependent random reads per lane and lives on memory-level parallelism:
+// 4 waves per block, up to 8 blocks per CU.
+#include "gs_common.h"
+
+namespace {
+
+struct SampleParams {
+    int n_hops;
+    int fan[GS_MAX_HOPS];
+    int size[GS_MAX_HOPS];      // slots per hop
+    int off[GS_MAX_HOPS];       // offset of the hop inside one walk's tape
+    int tape_len;               // words of tape per walk
+    int lds_per_buf;            // ints per LDS parent buffer (two per wave)
+    int32_t *out[GS_MAX_HOPS];
+};
+
+constexpr int kWavesPerBlock = 4;
+
+__global__ __launch_bounds__(kWavesPerBlock * 64)
+void sample_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                   int64_t n_nodes, const int32_t *__restrict__ seeds, int64_t n_seeds,
+                   SampleParams P, uint32_t key0, uint32_t key1, uint64_t walk_base,
+                   const int64_t *__restrict__ walk_ids, const uint32_t *__restrict__ replay,
+                   int32_t *__restrict__ err) {
+    extern __shared__ int32_t lds[];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (w >= n_seeds) return;                       // wave-uniform
+
+    int32_t *buf0 = lds + (size_t)wave * 2 * P.lds_per_buf;
+    int32_t *buf1 = buf0 + P.lds_per_buf;
+
+    int32_t root = seeds[w];
+    if ((uint64_t)(int64_t)root >= (uint64_t)n_nodes) {
+        if (lane == 0) atomicMax(&err[1], 1);
+        root = -1;
+    }
+    const uint64_t walk = walk_ids ? (uint64_t)walk_ids[w] : walk_base + (uint64_t)w;
+    const uint32_t wlo = (uint32_t)walk, whi = (uint32_t)(walk >> 32);
+    const uint32_t *tape = replay ? replay + (size_t)w * P.tape_len : nullptr;
+
+    for (int h = 0; h < P.n_hops; ++h) {
+        const int k = P.fan[h];
+        const int total = P.size[h];
+        const int32_t *par = (h & 1) ? buf0 : buf1;         // ids of hop h-1
+        int32_t *cur = (h & 1) ? buf1 : buf0;               // ids of hop h
+        const bool keep = h + 1 < P.n_hops;
+        int32_t *dst = P.out[h] + (size_t)w * total;
+        for (int t = lane; t < total; t += 64) {
+            const int32_t p = (h == 0) ? root : par[t / k];
+            int32_t v = -1;
+            if (p >= 0) {
+                const int64_t a = indptr[p];
+                const int64_t b = indptr[p + 1];
+                const uint32_t deg = (uint32_t)(b - a);
+                if (deg == 0) {
+                    atomicMax(&err[0], p + 1);
+                } else {
+                    const uint32_t r = tape ? tape[P.off[h] + t]
+                                            : gs::philox4x32_10_x(wlo, whi, (uint32_t)h, (uint32_t)t, key0, key1);
+                    v = indices[a + (int64_t)__umulhi(r, deg)];
+                }
+            }
+            dst[t] = v;
+            if (keep) cur[t] = v;
+        }
+        // make this hop's LDS writes visible to the other lanes of the wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_sample(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
+                         const int32_t *seeds, int64_t n_seeds,
+                         const int32_t *fanouts, int n_hops,
+                         uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
+                         const uint32_t *replay,
+                         int32_t *const *out_hops, int32_t *err_flag, void *stream) {
+    if (!indptr || !indices || !seeds || !fanouts || !out_hops || !err_flag)
+        return gs::fail(GS_EINVAL, "gs_sample: null pointer argument");
+    if (n_hops < 1 || n_hops > GS_MAX_HOPS)
+        return gs::fail(GS_EINVAL, "gs_sample: n_hops=%d outside [1,%d]", n_hops, GS_MAX_HOPS);
+    if (n_seeds < 0 || n_nodes <= 0 || n_nodes > 0x7FFFFFFELL)
+        return gs::fail(GS_EINVAL, "gs_sample: n_seeds=%lld n_nodes=%lld out of range",
+                        (long long)n_seeds, (long long)n_nodes);
+    if (n_seeds == 0) return GS_OK;
+
+    SampleParams P{};
+    P.n_hops = n_hops;
+    int64_t prod = 1, off = 0;
+    for (int h = 0; h < n_hops; ++h) {
+        if (fanouts[h] < 1) return gs::fail(GS_EINVAL, "gs_sample: fanouts[%d]=%d < 1", h, fanouts[h]);
+        if (!out_hops[h]) return gs::fail(GS_EINVAL, "gs_sample: out_hops[%d] is null", h);
+        prod *= fanouts[h];
+        if (prod > (1 << 24)) return gs::fail(GS_ELIMIT, "gs_sample: hop %d has more than 2^24 slots per walk", h);
+        P.fan[h] = fanouts[h];
+        P.size[h] = (int)prod;
+        P.off[h] = (int)off;
+        P.out[h] = out_hops[h];
+        off += prod;
+    }
+    P.tape_len = (int)off;
+    P.lds_per_buf = n_hops >= 2 ? P.size[n_hops - 2] : 1;
+    const size_t lds_bytes = (size_t)kWavesPerBlock * 2 * P.lds_per_buf * sizeof(int32_t);
+    if (lds_bytes > 64 * 1024)
+        return gs::fail(GS_ELIMIT, "gs_sample: %d parent slots per walk need %zu B of LDS per block (limit 65536)",
+                        P.lds_per_buf, lds_bytes);
+    const int64_t blocks = (n_seeds + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 0x7FFFFFFFLL) return gs::fail(GS_ELIMIT, "gs_sample: too many seeds for one launch");
+
+    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(kWavesPerBlock * 64), lds_bytes,
+                       (hipStream_t)stream, indptr, indices, n_nodes, seeds, n_seeds, P,
+                       (uint32_t)rng_seed, (uint32_t)(rng_seed >> 32), walk_id_base, walk_ids, replay,
+                       err_flag);
+    return gs::check_launch("gs_sample");
+}

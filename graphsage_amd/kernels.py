@@ -1,0 +1,209 @@
+"""Tensor-level wrappers over the C ABI.
+
+torch tensors are only the carrier of device memory here: every function checks
+device, dtype, contiguity and shapes on the host (a kernel that is handed a
+shape it does not expect faults the GPU), then passes raw pointers and the
+current HIP stream to ``libgsage.so``.  Nothing in this file computes.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT, check, load, ptr, stream_handle
+
+
+def _dev(t, dtype, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch tensor" % name)
+    if not t.is_cuda:
+        raise _lib.GsageError("%s must live on the GPU (got %s)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must have %d dimensions (got %d)" % (name, ndim, t.dim()))
+    return t
+
+
+def hop_sizes(fanouts):
+    out, p = [], 1
+    for n in fanouts:
+        p *= int(n)
+        out.append(p)
+    return out
+
+
+def sample(indptr, indices, seeds, fanouts, rng_seed=0, walk_id_base=0, walk_ids=None, replay=None,
+           err_flag=None):
+    """Multi-hop sampling; returns (list of int32 [n_seeds, size_h] tensors, err_flag)."""
+    lib = load()
+    _dev(indptr, torch.int64, 'indptr', 1)
+    _dev(indices, torch.int32, 'indices', 1)
+    _dev(seeds, torch.int32, 'seeds', 1)
+    fanouts = [int(f) for f in fanouts]
+    if not 1 <= len(fanouts) <= _lib.GS_MAX_HOPS:
+        raise ValueError("between 1 and %d hops are supported" % _lib.GS_MAX_HOPS)
+    if any(f < 1 for f in fanouts):
+        raise ValueError("fan-outs must be positive")
+    n_nodes = indptr.numel() - 1
+    n_seeds = seeds.numel()
+    sizes = hop_sizes(fanouts)
+    if walk_ids is not None:
+        _dev(walk_ids, torch.int64, 'walk_ids', 1)
+        if walk_ids.numel() != n_seeds:
+            raise ValueError("walk_ids must have one entry per seed")
+    if replay is not None:
+        _dev(replay, torch.int32, 'replay', 1)       # uint32 words carried in an int32 tensor
+        if replay.numel() != n_seeds * sum(sizes):
+            raise ValueError("replay tape must hold %d words (got %d)" % (n_seeds * sum(sizes), replay.numel()))
+    if err_flag is None:
+        err_flag = torch.zeros(2, dtype=torch.int32, device=seeds.device)
+    else:
+        _dev(err_flag, torch.int32, 'err_flag', 1)
+    hops = [torch.empty((n_seeds, s), dtype=torch.int32, device=seeds.device) for s in sizes]
+    fan_arr = (ctypes.c_int32 * len(fanouts))(*fanouts)
+    out_arr = (ctypes.c_void_p * len(hops))(*[h.data_ptr() for h in hops])
+    check(lib.gs_sample(ptr(indptr), ptr(indices), n_nodes, ptr(seeds), n_seeds, fan_arr, len(fanouts),
+                        int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(walk_id_base) & 0xFFFFFFFFFFFFFFFF,
+                        ptr(walk_ids), ptr(replay), out_arr, ptr(err_flag), stream_handle()), 'gs_sample')
+    return hops, err_flag
+
+
+def gather_rows(feat, ids, id_offset=0, out=None):
+    lib = load()
+    _dev(feat, torch.float32, 'feat', 2)
+    _dev(ids, torch.int32, 'ids')
+    n, f = ids.numel(), feat.shape[1]
+    if out is None:
+        out = torch.empty((n, f), dtype=torch.float32, device=feat.device)
+    else:
+        _dev(out, torch.float32, 'out')
+        if out.numel() != n * f:
+            raise ValueError("out has %d elements, %d needed" % (out.numel(), n * f))
+    check(lib.gs_gather_rows(ptr(feat), feat.shape[0], f, int(id_offset), ptr(ids), n, ptr(out),
+                             stream_handle()), 'gs_gather_rows')
+    return out
+
+
+def gather_mean(feat, child_ids, n_parents, n_child, id_offset=0, out=None):
+    """child_ids None: dense groups (parent p owns rows p*n_child .. of feat)."""
+    lib = load()
+    _dev(feat, torch.float32, 'feat', 2)
+    f = feat.shape[1]
+    if child_ids is not None:
+        _dev(child_ids, torch.int32, 'child_ids')
+        if child_ids.numel() != n_parents * n_child:
+            raise ValueError("child_ids has %d entries, %d needed" % (child_ids.numel(), n_parents * n_child))
+    elif n_parents * n_child > feat.shape[0]:
+        raise ValueError("dense groups need n_parents*n_child <= rows of feat")
+    if out is None:
+        out = torch.empty((n_parents, f), dtype=torch.float32, device=feat.device)
+    else:
+        _dev(out, torch.float32, 'out')
+        if out.numel() != n_parents * f:
+            raise ValueError("out has %d elements, %d needed" % (out.numel(), n_parents * f))
+    check(lib.gs_gather_mean_fwd(ptr(feat), feat.shape[0], f, int(id_offset), ptr(child_ids), n_parents,
+                                 n_child, ptr(out), stream_handle()), 'gs_gather_mean_fwd')
+    return out
+
+
+def gather_mean_bwd(g_mean, child_ids, n_child, g_feat, id_offset=0):
+    """Adds (child_ids given) or stores (dense) g_mean / n_child into g_feat rows."""
+    lib = load()
+    _dev(g_mean, torch.float32, 'g_mean', 2)
+    _dev(g_feat, torch.float32, 'g_feat', 2)
+    n_parents, f = g_mean.shape
+    if g_feat.shape[1] != f:
+        raise ValueError("feature widths differ")
+    if child_ids is not None:
+        _dev(child_ids, torch.int32, 'child_ids')
+        if child_ids.numel() != n_parents * n_child:
+            raise ValueError("child_ids has %d entries, %d needed" % (child_ids.numel(), n_parents * n_child))
+    elif n_parents * n_child > g_feat.shape[0]:
+        raise ValueError("dense groups need n_parents*n_child <= rows of g_feat")
+    check(lib.gs_gather_mean_bwd(ptr(g_mean), ptr(child_ids), n_parents, n_child, f, int(id_offset),
+                                 g_feat.shape[0], ptr(g_feat), stream_handle()), 'gs_gather_mean_bwd')
+    return g_feat
+
+
+def _project_args(x_self, x_mean, w_self, w_neigh, bias):
+    _dev(x_self, torch.float32, 'x_self', 2)
+    _dev(x_mean, torch.float32, 'x_mean', 2)
+    _dev(w_self, torch.float32, 'w_self', 2)
+    _dev(w_neigh, torch.float32, 'w_neigh', 2)
+    m, fs = x_self.shape
+    fn = x_mean.shape[1]
+    if x_mean.shape[0] != m:
+        raise ValueError("x_self and x_mean must have the same number of rows")
+    hh = w_self.shape[1]
+    if w_self.shape[0] != fs or w_neigh.shape != (fn, hh):
+        raise ValueError("weight shapes %s / %s do not match inputs (%d, %d)" %
+                         (tuple(w_self.shape), tuple(w_neigh.shape), fs, fn))
+    if bias is not None:
+        _dev(bias, torch.float32, 'bias', 1)
+        if bias.numel() != 2 * hh:
+            raise ValueError("bias must have %d entries" % (2 * hh))
+    return m, fs, fn, 2 * hh
+
+
+def sage_project(x_self, x_mean, w_self, w_neigh, bias, act, out=None):
+    lib = load()
+    m, fs, fn, h = _project_args(x_self, x_mean, w_self, w_neigh, bias)
+    if out is None:
+        out = torch.empty((m, h), dtype=torch.float32, device=x_self.device)
+    else:
+        _dev(out, torch.float32, 'out')
+        if out.numel() != m * h:
+            raise ValueError("out has %d elements, %d needed" % (out.numel(), m * h))
+    check(lib.gs_sage_project_fwd(ptr(x_self), fs, ptr(x_mean), fn, m, ptr(w_self), ptr(w_neigh), ptr(bias),
+                                  h, ACT[act], ptr(out), stream_handle()), 'gs_sage_project_fwd')
+    return out
+
+
+def sage_project_bwd(x_self, x_mean, w_self, w_neigh, act, out, g_out, need_x_self=True, need_x_mean=True,
+                     need_bias=True):
+    lib = load()
+    m, fs, fn, h = _project_args(x_self, x_mean, w_self, w_neigh, None)
+    _dev(g_out, torch.float32, 'g_out', 2)
+    if tuple(g_out.shape) != (m, h):
+        raise ValueError("g_out must be (%d, %d)" % (m, h))
+    if out is not None:
+        _dev(out, torch.float32, 'out', 2)
+        if tuple(out.shape) != (m, h):
+            raise ValueError("out must be (%d, %d)" % (m, h))
+    dev = x_self.device
+    g_ws = torch.empty_like(w_self)
+    g_wn = torch.empty_like(w_neigh)
+    g_b = torch.empty(h, dtype=torch.float32, device=dev) if need_bias else None
+    g_xs = torch.empty_like(x_self) if need_x_self else None
+    g_xm = torch.empty_like(x_mean) if need_x_mean else None
+    ws_bytes = lib.gs_sage_project_bwd_workspace(fs, fn, h, m)
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dev)
+    check(lib.gs_sage_project_bwd(ptr(x_self), fs, ptr(x_mean), fn, m, ptr(w_self), ptr(w_neigh), h, ACT[act],
+                                  ptr(out), ptr(g_out), ptr(g_ws), ptr(g_wn), ptr(g_b), ptr(g_xs), ptr(g_xm),
+                                  ptr(ws), ws.numel() * 4, stream_handle()), 'gs_sage_project_bwd')
+    return g_ws, g_wn, g_b, g_xs, g_xm
+
+
+def l2_normalize(x, out=None):
+    lib = load()
+    _dev(x, torch.float32, 'x', 2)
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.gs_l2_normalize_fwd(ptr(x), x.shape[0], x.shape[1], ptr(out), stream_handle()),
+          'gs_l2_normalize_fwd')
+    return out
+
+
+def l2_normalize_bwd(x, g_out):
+    lib = load()
+    _dev(x, torch.float32, 'x', 2)
+    _dev(g_out, torch.float32, 'g_out', 2)
+    if g_out.shape != x.shape:
+        raise ValueError("shapes differ")
+    g_x = torch.empty_like(x)
+    check(lib.gs_l2_normalize_bwd(ptr(x), ptr(g_out), x.shape[0], x.shape[1], ptr(g_x), stream_handle()),
+          'gs_l2_normalize_bwd')
+    return g_x

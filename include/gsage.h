@@ -1,0 +1,153 @@
+/*
+ * libgsage.so -- C ABI of the MI355X (gfx950) bipartite GraphSAGE hot path.
+ *
+ * The reference project is pure Python and has no FFI of its own; the Python
+ * host in graphsage_amd/ keeps the reference's classes and calls the entry
+ * points below through ctypes.  Each entry point names the reference lines
+ * whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer marked "device" is device memory owned by the caller; the
+ *     library never allocates, frees or keeps device memory;
+ *   - work is enqueued on the caller's hipStream_t (`stream`, may be NULL for
+ *     the default stream); no entry point synchronises;
+ *   - node ids are int32, row counts and CSR offsets int64;
+ *   - return value 0 = GS_OK, negative = error, text in gs_last_error()
+ *     (thread-local, valid until the next failing call on that thread);
+ *   - the only global state is that thread-local error text: entry points are
+ *     re-entrant and may be called from several host threads and streams.
+ */
+#ifndef GSAGE_H_
+#define GSAGE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_OK        0
+#define GS_EINVAL   (-1)   /* null pointer, negative size, unsupported shape    */
+#define GS_ELAUNCH  (-2)   /* the HIP runtime refused the launch                */
+#define GS_ELIMIT   (-3)   /* a size exceeds what the kernels were built for   */
+
+#define GS_MAX_HOPS  4
+
+/* activation codes of gs_sage_project_*: models.py:69 uses "relu" for all but
+ * the last layer and "linear" for the last. */
+#define GS_ACT_LINEAR 0
+#define GS_ACT_RELU   1
+
+int gs_version(void);
+const char *gs_last_error(void);
+
+/*
+ * Multi-hop uniform neighbor sampling with replacement over a CSR.
+ * Replaces BreadthFirstWalker.run_breadth_first_walk (sampler.py:47-96) and the
+ * dict lookups it makes (bipartite_graph.py:62-68); writing hop h of all walks
+ * as one dense [n_seeds, fanouts[0]*...*fanouts[h]] array in breadth-first
+ * (= slot) order also replaces the regroup of generator.py:314-333.
+ *
+ *   indptr   device int64[n_nodes+1], indices device int32[indptr[n_nodes]]:
+ *            neighbors of v are indices[indptr[v] .. indptr[v+1]) in the order
+ *            the reference's neighbor_dict lists them (bipartite_graph.py:56-58)
+ *   seeds    device int32[n_seeds] roots (the generator passes all source heads
+ *            followed by all destination heads, generator.py:301-309)
+ *   fanouts  HOST int32[n_hops], 1 <= n_hops <= GS_MAX_HOPS
+ *   draw for (walk, hop, slot):
+ *            replay != NULL: r = replay[w*T + off[hop] + slot], w = index of the
+ *                     seed in this call, T = sum of the hop sizes, off[h] = sum
+ *                     of the sizes of hops < h  (the order in which the
+ *                     reference consumes its random stream, sampler.py:65-90)
+ *            replay == NULL: r = Philox4x32-10(counter = (walk_lo, walk_hi, hop,
+ *                     slot), key = rng_seed)[0], walk = walk_ids ? walk_ids[w]
+ *                     : walk_id_base + w
+ *            neighbor index = (r * degree) >> 32
+ *   out_hops HOST array of n_hops device pointers, out_hops[h] = int32[n_seeds *
+ *            size[h]]
+ *   err_flag device int32[2], zeroed by the caller: [0] becomes 1 + the largest
+ *            node id that was asked for samples but has no neighbors (the
+ *            reference raises for it, sampler.py:81-82); [1] becomes 1 if a seed
+ *            lies outside [0, n_nodes).  Samples below such a node are -1.
+ */
+int gs_sample(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
+              const int32_t *seeds, int64_t n_seeds,
+              const int32_t *fanouts, int n_hops,
+              uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
+              const uint32_t *replay,
+              int32_t *const *out_hops, int32_t *err_flag, void *stream);
+
+/*
+ * out[i, :] = feat[ids[i] - id_offset, :].
+ * Replaces Graph.get_node_features_from_node (bipartite_graph.py:70-76; id_offset
+ * is its correction_constant for items, 0 for users) as called from
+ * GraphSAGEGenerator._get_features (generator.py:270-273).
+ * Rows outside [0, n_rows) (e.g. the -1 ids below an isolated node) give zeros.
+ */
+int gs_gather_rows(const float *feat, int64_t n_rows, int F, int64_t id_offset,
+                   const int32_t *ids, int64_t n, float *out, void *stream);
+
+/*
+ * out_mean[p, :] = (1/n_child) * sum_j feat[child_ids[p*n_child + j] - id_offset, :]
+ * The feature gather above fused with the neighbor mean of Aggregator.call
+ * (utils.py:103-109, K.mean over axis 2): the (B, heads, n, F) neighbor tensor
+ * the reference materialises is never written.
+ * child_ids == NULL means the children of parent p are rows p*n_child .. +n_child
+ * of feat (the layer >= 1 case, where the neighbor input is already a dense
+ * activation tensor, models.py:151-160).
+ */
+int gs_gather_mean_fwd(const float *feat, int64_t n_rows, int F, int64_t id_offset,
+                       const int32_t *child_ids, int64_t n_parents, int n_child,
+                       float *out_mean, void *stream);
+
+/*
+ * Backward of gs_gather_mean_fwd with respect to feat:
+ *   g_feat[child - id_offset, :] += g_mean[p, :] / n_child      (float atomics)
+ * child_ids == NULL: g_feat[p*n_child + j, :] = g_mean[p, :] / n_child (plain
+ * stores, every row written exactly once).  No reference counterpart beyond
+ * TensorFlow's autodiff of utils.py:109.
+ */
+int gs_gather_mean_bwd(const float *g_mean, const int32_t *child_ids, int64_t n_parents,
+                       int n_child, int F, int64_t id_offset, int64_t n_rows,
+                       float *g_feat, void *stream);
+
+/*
+ * out[m, :] = act(concat(x_self[m, :] @ W_self, x_mean[m, :] @ W_neigh) + bias)
+ * The projection part of Aggregator.call (utils.py:109,114-119) with weights
+ * shaped as Aggregator.build makes them (utils.py:72-89): W_self [Fs, H/2],
+ * W_neigh [Fn, H/2], bias [H] or NULL, all row-major device float.  H even.
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ */
+int gs_sage_project_fwd(const float *x_self, int Fs, const float *x_mean, int Fn, int64_t M,
+                        const float *W_self, const float *W_neigh, const float *bias,
+                        int H, int act, float *out, void *stream);
+
+/*
+ * Backward of gs_sage_project_fwd.  `out` is the forward result (needed for the
+ * relu mask), g_out its gradient.  Any of the g_* outputs may be NULL to skip
+ * it.  g_W_self / g_W_neigh / g_bias are overwritten (not accumulated).
+ * workspace: device scratch of at least gs_sage_project_bwd_workspace() bytes,
+ * used for per-block partial sums that a second kernel adds in a fixed order,
+ * so weight gradients are bitwise reproducible.
+ */
+size_t gs_sage_project_bwd_workspace(int Fs, int Fn, int H, int64_t M);
+int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_mean, int Fn, int64_t M,
+                        const float *W_self, const float *W_neigh, int H, int act,
+                        const float *out, const float *g_out,
+                        float *g_W_self, float *g_W_neigh, float *g_bias,
+                        float *g_x_self, float *g_x_mean,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * out[m, :] = x[m, :] * rsqrt(max(sum(x[m, :]^2), 1e-12)) -- K.l2_normalize as
+ * applied to the final embeddings (models.py:32,186-190) -- and its backward.
+ */
+int gs_l2_normalize_fwd(const float *x, int64_t M, int H, float *out, void *stream);
+int gs_l2_normalize_bwd(const float *x, const float *g_out, int64_t M, int H,
+                        float *g_x, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSAGE_H_ */

@@ -1,0 +1,403 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle -- needs a GPU.
+
+Integer work (sampling, regroup, gather) is compared bit for bit; floating-point
+work (neighbor mean, projection, embeddings, gradients) within 1e-5 relative to
+the float64 oracle, the tolerance the project states for fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_graph_parts
+import graphsage_amd as ga
+from graphsage_amd import kernels
+from oracle import generator as ogen
+from oracle import model as omodel
+from oracle import walker
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def close(got, want, rtol=RTOL, scale=None):
+    """|got - want| <= rtol * max(|want|) (per tensor): fp32 sums of O(1) terms."""
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
+    want = want.detach().cpu().double().numpy() if isinstance(want, torch.Tensor) else np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    s = scale if scale is not None else max(float(np.abs(want).max()), 1e-30)
+    err = float(np.abs(got - want).max())
+    assert err <= rtol * s, "max abs err %.3e > %.1e * %.3e" % (err, rtol, s)
+
+
+def csr_of(g):
+    return np.asarray(g.indptr), np.asarray(g.indices)
+
+
+# ---------------------------------------------------------------- sampler ----
+
+@pytest.mark.parametrize('case', range(7))
+def test_sampler_replay_is_bit_exact_with_reference(golden, cuda, case):
+    arrays, meta = golden
+    info = meta['replay'][case]
+    key, ns = info['key'], info['num_samples']
+    g = ga.Graph(*golden_graph_parts(arrays, info['graph']))
+    links = arrays[key + '_links']
+    roots = np.concatenate([links[:, 0], links[:, 1]]).astype(np.int32)
+    dev = g.device_tensors()
+    tape = torch.from_numpy(arrays[key + '_tape'].view(np.int32)).to(cuda)
+    hops, err = kernels.sample(dev['indptr'], dev['indices'], torch.from_numpy(roots).to(cuda), ns, replay=tape)
+    assert err.tolist() == [0, 0]
+    for h in range(len(ns)):
+        np.testing.assert_array_equal(hops[h].cpu().numpy(), arrays[key + '_hop%d' % (h + 1)])
+
+
+@pytest.mark.parametrize('case', range(3))
+def test_walker_replay_returns_reference_walk_lists(golden, cuda, case):
+    arrays, meta = golden
+    info = meta['walker_only'][case]
+    key, ns = info['key'], info['num_samples']
+    g = ga.Graph(*golden_graph_parts(arrays, info['graph']))
+    roots = [int(r) for r in arrays[key + '_roots']]
+    w = ga.BreadthFirstWalker(g, ns)
+    w.set_replay(arrays[key + '_tape'])
+    walks = w.run_breadth_first_walk(roots)
+    hops = walker.walks_to_hops(walks, ns)
+    for h in range(len(ns)):
+        np.testing.assert_array_equal(hops[h], arrays[key + '_hop%d' % (h + 1)])
+    if case == 0:
+        assert walks == meta['walk0_nested']
+
+
+def test_walker_known_answer_walk(golden, cuda):
+    """The reference's own walk for random.seed(7), replayed from the uniforms
+    that seed produced (word = floor(u * 2**32); exact for these tiny degrees)."""
+    arrays, meta = golden
+    feats = {'user': arrays['kat_feat_user'], 'item': arrays['kat_feat_item']}
+    g = ga.Graph(feats, {'user': [0, 1, 2], 'item': [3, 4]}, arrays['kat_edges'])
+    w = ga.BreadthFirstWalker(g, [3, 2])
+    w.set_replay(np.floor(np.asarray(meta['kat_uniforms_seed7']) * 2.0 ** 32).astype(np.uint32))
+    assert w.run_breadth_first_walk([0, 4]) == meta['kat_walk_seed7']
+
+
+@pytest.mark.parametrize('ns', [[25, 10], [4, 3, 2], [70, 3], [5], [3, 2, 2, 2]])
+def test_sampler_philox_matches_oracle(golden, cuda, ns):
+    arrays, _ = golden
+    g = ga.Graph(*golden_graph_parts(arrays, 'g_mid'))
+    indptr, indices = csr_of(g)
+    rng = np.random.default_rng(5)
+    roots = rng.integers(0, g.num_nodes, 301).astype(np.int32)
+    dev = g.device_tensors()
+    seed, base = 0xDEADBEEFCAFEF00D, (1 << 33) + 12345
+    hops, err = kernels.sample(dev['indptr'], dev['indices'], torch.from_numpy(roots).to(cuda), ns,
+                               rng_seed=seed, walk_id_base=base)
+    assert err.tolist() == [0, 0]
+    want = walker.walk_vectorised(indptr, indices, roots, ns, rng_seed=seed, first_walk=base)
+    for got, w in zip(hops, want):
+        np.testing.assert_array_equal(got.cpu().numpy(), w)
+    # explicit walk ids: draws follow the id, not the position in the batch
+    perm = rng.permutation(len(roots))
+    ids = torch.from_numpy((base + perm).astype(np.int64)).to(cuda)
+    hops2, _ = kernels.sample(dev['indptr'], dev['indices'], torch.from_numpy(roots[perm]).to(cuda), ns,
+                              rng_seed=seed, walk_ids=ids)
+    for got, w in zip(hops2, want):
+        np.testing.assert_array_equal(got.cpu().numpy(), w[perm])
+
+
+def test_sampler_isolated_node_and_bad_seed(golden, cuda):
+    edges = np.array([[0, 1, 3, 3], [3, 3, 0, 1]])
+    feats = {'user': np.zeros((3, 2), np.float32), 'item': np.zeros((2, 2), np.float32)}
+    g = ga.Graph(feats, {'user': [0, 1, 2], 'item': [3, 4]}, edges)
+    w = ga.BreadthFirstWalker(g, [2, 2])
+    with pytest.raises(KeyError):
+        w.run_breadth_first_walk([2])
+    with pytest.raises(ValueError) as ei:
+        w.run_breadth_first_walk([0, 2])
+    assert str(ei.value).startswith("Samples must exist. Self-node also can be a sample")
+    assert w.run_breadth_first_walk([]) == []
+    with pytest.raises(KeyError):
+        w.run_breadth_first_walk([7])
+    dev = g.device_tensors()
+    hops, err = kernels.sample(dev['indptr'], dev['indices'],
+                               torch.tensor([0, 2, 99, -4], dtype=torch.int32, device=cuda), [2, 2])
+    assert err.tolist() == [3, 1]                      # 1 + isolated node 2; an out-of-range seed was seen
+    assert (hops[0][1:] == -1).all() and (hops[1][1:] == -1).all() and (hops[0][0] >= 0).all()
+    # empty input
+    hops, err = kernels.sample(dev['indptr'], dev['indices'], torch.zeros(0, dtype=torch.int32, device=cuda), [2, 2])
+    assert hops[0].shape == (0, 2) and hops[1].shape == (0, 4)
+
+
+@pytest.mark.parametrize('case', range(7))
+def test_generator_batches_equal_reference_arrays(golden, cuda, case):
+    """flow()/sample_features on replayed draws: the six slot tensors equal the
+    arrays the reference generator produced, element for element."""
+    arrays, meta = golden
+    info = meta['replay'][case]
+    key, ns, b = info['key'], info['num_samples'], info['batch']
+    g = ga.Graph(*golden_graph_parts(arrays, info['graph']))
+    links = [tuple(int(v) for v in l) for l in arrays[key + '_links']]
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'])
+    gen.sampler.set_replay(arrays[key + '_tape'])
+    batch = gen.sample_features(links, 0)
+    assert len(batch) == 2 * (len(ns) + 1)
+    for i in range(len(batch)):
+        want = arrays[key + '_x%d' % i]
+        assert tuple(batch[i].shape) == want.shape
+        np.testing.assert_array_equal(batch[i].cpu().numpy(), want)
+    # through flow(): same thing, targets ride along
+    gen.sampler.set_replay(arrays[key + '_tape'])
+    seq = gen.flow(links, targets=np.arange(b), shuffle=False)
+    feats, targets = seq[0]
+    np.testing.assert_array_equal(targets, np.arange(b))
+    np.testing.assert_array_equal(feats[len(feats) - 1].cpu().numpy(), arrays[key + '_x%d' % (len(feats) - 1)])
+
+
+def test_generator_known_answer_shapes_and_values(golden, cuda):
+    arrays, meta = golden
+    feats = {'user': arrays['kat_feat_user'], 'item': arrays['kat_feat_item']}
+    g = ga.Graph(feats, {'user': [0, 1, 2], 'item': [3, 4]}, arrays['kat_edges'])
+    gen = ga.GraphSAGEGenerator(g, 2, [3, 2], head_node_types=['user', 'item'])
+    import random
+    random.seed(3)
+    us = [random.random() for _ in range(2 * 2 * 9)]
+    gen.sampler.set_replay(np.floor(np.asarray(us) * 2.0 ** 32).astype(np.uint32))
+    seq = gen.flow([(0, 3), (2, 4), (1, 3)], targets=[1, 0, 1])
+    assert len(seq) == meta['kat_gen_seed3_len']
+    f0, t0 = seq[0]
+    assert [list(f0[i].shape) for i in range(6)] == meta['kat_gen_seed3_shapes']
+    assert [int(t) for t in t0] == meta['kat_gen_seed3_targets']
+    for i in range(6):
+        np.testing.assert_array_equal(f0[i].cpu().numpy(), arrays['kat_gen_seed3_x%d' % i].astype(np.float32))
+
+
+def test_sampling_is_independent_of_batch_split_and_rank(golden, cuda):
+    """Draws are keyed by (link position, side, hop, slot): the same link gets
+    the same neighborhood whether it is sampled in one batch, in small batches
+    or on another rank of a data-parallel run."""
+    arrays, _ = golden
+    g = ga.Graph(*golden_graph_parts(arrays, 'g_mid'))
+    e = arrays['g_mid_edges']
+    links = [(int(e[0, i]), int(e[1, i])) for i in range(40)]
+    targets = np.arange(40)
+
+    def collect(batch_size, rank=0, world=1):
+        gen = ga.GraphSAGEGenerator(g, batch_size, [5, 3], head_node_types=['user', 'item'], seed=11)
+        seq = gen.flow(links, targets=targets, shuffle=True, seed=3, rank=rank, world_size=world)
+        out = {}
+        for feats, t in seq:
+            ids = [x.cpu().numpy() for x in feats.ids]
+            for r, link in enumerate(t):
+                out[int(link)] = [a[r].copy() for a in ids]
+        return out
+
+    whole = collect(40)
+    small = collect(7)
+    r0, r1 = collect(8, 0, 2), collect(8, 1, 2)
+    assert sorted(list(r0) + list(r1)) == list(range(40)) and not set(r0) & set(r1)
+    for link in range(40):
+        other = r0.get(link) or r1.get(link)
+        for a, b, c in zip(whole[link], small[link], other):
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(a, c)
+    # a new epoch resamples
+    gen = ga.GraphSAGEGenerator(g, 40, [5, 3], seed=11)
+    seq = gen.flow(links, targets=targets, shuffle=False)
+    a = seq[0][0].ids[4].cpu().numpy()
+    seq.on_epoch_end()
+    assert not np.array_equal(a, seq[0][0].ids[4].cpu().numpy())
+
+
+# ------------------------------------------------------------ gather-mean ----
+
+@pytest.mark.parametrize('f', [64, 24, 19, 30, 18, 256, 300, 1])
+@pytest.mark.parametrize('n_child', [10, 25, 1, 9])
+def test_gather_rows_and_gather_mean(cuda, f, n_child):
+    rng = np.random.default_rng(f * 100 + n_child)
+    n_rows, n_parents, off = 777, 133, 1000
+    feat = rng.standard_normal((n_rows, f)).astype(np.float32)
+    ids = rng.integers(0, n_rows, n_parents * n_child).astype(np.int32) + off
+    ids[3] = -1                                           # below an isolated node: contributes zeros
+    ids[5] = off + n_rows                                 # out of range on the other side
+    d_feat, d_ids = torch.from_numpy(feat).to(cuda), torch.from_numpy(ids).to(cuda)
+    rows = kernels.gather_rows(d_feat, d_ids, off).cpu().numpy()
+    valid = (ids - off >= 0) & (ids - off < n_rows)
+    want_rows = np.where(valid[:, None], feat[np.clip(ids - off, 0, n_rows - 1)], 0).astype(np.float32)
+    np.testing.assert_array_equal(rows, want_rows)        # a copy: bit exact
+    got = kernels.gather_mean(d_feat, d_ids, n_parents, n_child, off)
+    want = want_rows.astype(np.float64).reshape(n_parents, n_child, f).mean(axis=1)
+    close(got, want, scale=1.0)
+    # dense groups give the same bits as the indexed form on materialised rows
+    dense = kernels.gather_mean(torch.from_numpy(want_rows).to(cuda), None, n_parents, n_child)
+    assert torch.equal(dense, got)
+    # empty input
+    assert kernels.gather_mean(d_feat, d_ids[:0], 0, n_child, off).shape == (0, f)
+    assert kernels.gather_rows(d_feat, d_ids[:0], off).shape == (0, f)
+
+
+def test_gather_mean_many_children_and_unaligned_views(cuda):
+    rng = np.random.default_rng(1)
+    feat = rng.standard_normal((50, 64)).astype(np.float32)
+    ids = rng.integers(0, 50, 7 * 1000).astype(np.int32)           # child tile too large for LDS staging
+    d = torch.from_numpy(feat).to(cuda)
+    got = kernels.gather_mean(d, torch.from_numpy(ids).to(cuda), 7, 1000)
+    close(got, feat[ids].astype(np.float64).reshape(7, 1000, 64).mean(1), scale=1.0)
+    # a table whose base is only 4-byte aligned falls back to scalar lanes
+    buf = torch.zeros(50 * 64 + 1, dtype=torch.float32, device=cuda)
+    buf[1:] = d.reshape(-1)
+    view = buf[1:].reshape(50, 64)
+    got2 = kernels.gather_mean(view, torch.from_numpy(ids).to(cuda), 7, 1000)
+    close(got2, got, rtol=1e-6, scale=1.0)
+
+
+def test_gather_mean_backward_scatter_add(cuda):
+    rng = np.random.default_rng(2)
+    n_rows, f, n_parents, n_child, off = 40, 24, 64, 10, 7
+    ids = rng.integers(0, n_rows, n_parents * n_child).astype(np.int32) + off
+    g = rng.standard_normal((n_parents, f)).astype(np.float32)
+    want = np.zeros((n_rows, f))
+    np.add.at(want, ids - off, np.repeat(g.astype(np.float64) / n_child, n_child, axis=0))
+    g_feat = torch.zeros((n_rows, f), dtype=torch.float32, device=cuda)
+    kernels.gather_mean_bwd(torch.from_numpy(g).to(cuda), torch.from_numpy(ids).to(cuda), n_child, g_feat, off)
+    close(g_feat, want, scale=float(np.abs(want).max()))
+    dense = torch.empty((n_parents * n_child, f), dtype=torch.float32, device=cuda)
+    kernels.gather_mean_bwd(torch.from_numpy(g).to(cuda), None, n_child, dense)
+    close(dense, np.repeat(g.astype(np.float64) / n_child, n_child, axis=0))
+
+
+# -------------------------------------------------------------- projection ----
+
+SHAPES = [(213, 64, 64, 32), (200, 24, 19, 32), (200, 19, 24, 32), (1000, 32, 32, 32),
+          (77, 256, 256, 256), (65, 30, 18, 6), (1, 64, 64, 32), (130, 7, 3, 2), (64, 64, 64, 160)]
+
+
+@pytest.mark.parametrize('m,fs,fn,h', SHAPES)
+@pytest.mark.parametrize('act', ['relu', 'linear'])
+def test_projection_forward_and_backward(cuda, m, fs, fn, h, act):
+    gen = torch.Generator().manual_seed(m + fs + h)
+    xs = torch.randn(m, fs, generator=gen, dtype=torch.float64)
+    xm = torch.randn(m, fn, generator=gen, dtype=torch.float64)
+    ws = omodel.glorot_uniform(fs, h // 2, gen, torch.float64).requires_grad_(True)
+    wn = omodel.glorot_uniform(fn, h // 2, gen, torch.float64).requires_grad_(True)
+    bias = (torch.randn(h, generator=gen, dtype=torch.float64) * 0.1).requires_grad_(True)
+    xs.requires_grad_(True)
+    xm.requires_grad_(True)
+    want = omodel.aggregator(xs[:, None, :], xm[:, None, None, :], ws, wn, bias, act)[:, 0, :]
+    g = torch.randn(m, h, generator=gen, dtype=torch.float64)
+    want.backward(g)
+
+    f32 = lambda t: t.detach().float().to(cuda).contiguous()
+    out = kernels.sage_project(f32(xs), f32(xm), f32(ws), f32(wn), f32(bias), act)
+    scale = float(want.abs().max())
+    close(out, want, scale=scale)
+    # the relu mask must come from the oracle's pre-activation sign: away from 0 both agree
+    g_ws, g_wn, g_b, g_xs, g_xm = kernels.sage_project_bwd(f32(xs), f32(xm), f32(ws), f32(wn), act, out, f32(g))
+    if act == 'relu' and not bool(((out.cpu() > 0) == (want > 0)).all()):
+        pytest.skip("a pre-activation within rounding of zero: mask differs legitimately")
+    close(g_ws, ws.grad)
+    close(g_wn, wn.grad)
+    close(g_b, bias.grad)
+    close(g_xs, xs.grad, scale=float(xs.grad.abs().max()) + 1e-30)
+    close(g_xm, xm.grad, scale=float(xm.grad.abs().max()) + 1e-30)
+    # no bias, skipped input gradients
+    out_nb = kernels.sage_project(f32(xs), f32(xm), f32(ws), f32(wn), None, act)
+    close(out_nb, omodel.aggregator(xs[:, None, :], xm[:, None, None, :], ws, wn, None, act)[:, 0, :], scale=scale)
+    r = kernels.sage_project_bwd(f32(xs), f32(xm), f32(ws), f32(wn), act, out, f32(g), need_x_self=False,
+                                 need_x_mean=False, need_bias=False)
+    assert r[2] is None and r[3] is None and r[4] is None
+    assert torch.equal(r[0], g_ws) and torch.equal(r[1], g_wn)     # slab reduction: reproducible bits
+
+
+def test_projection_rejects_bad_shapes(cuda):
+    z = lambda *s: torch.zeros(*s, device=cuda)
+    with pytest.raises(ValueError):
+        kernels.sage_project(z(4, 8), z(5, 8), z(8, 4), z(8, 4), None, 'relu')
+    with pytest.raises(ValueError):
+        kernels.sage_project(z(4, 8), z(4, 8), z(7, 4), z(8, 4), None, 'relu')
+    with pytest.raises(TypeError):
+        kernels.sage_project(z(4, 8).double(), z(4, 8), z(8, 4), z(8, 4), None, 'relu')
+    with pytest.raises(Exception):
+        kernels.sage_project(z(4, 8).cpu(), z(4, 8), z(8, 4), z(8, 4), None, 'relu')
+    assert kernels.sage_project(z(0, 8), z(0, 8), z(8, 4), z(8, 4), None, 'relu').shape == (0, 8)
+
+
+def test_l2_normalize_forward_backward(cuda):
+    gen = torch.Generator().manual_seed(0)
+    for m, h in [(100, 32), (3, 256), (5, 1), (64, 70)]:
+        x = torch.randn(m, h, generator=gen, dtype=torch.float64)
+        x[0] = 0                                      # the eps branch
+        x.requires_grad_(True)
+        want = omodel.l2_normalize(x)
+        g = torch.randn(m, h, generator=gen, dtype=torch.float64)
+        want.backward(g)
+        xf = x.detach().float().to(cuda)
+        close(kernels.l2_normalize(xf), want, scale=1.0)
+        close(kernels.l2_normalize_bwd(xf, g.float().to(cuda)), x.grad, scale=float(x.grad.abs().max()))
+
+
+# ------------------------------------------------------------------- model ----
+
+def _oracle_model(model, plan):
+    weights = {}
+    for layer, aggs in enumerate(model._aggs):
+        for node_type, agg in aggs.items():
+            weights[(layer, node_type)] = {
+                'w_self': agg.w_self.detach().cpu().double().requires_grad_(True),
+                'w_neigh': agg.w_neigh.detach().cpu().double().requires_grad_(True),
+                'bias': None if agg.bias is None else agg.bias.detach().cpu().double().requires_grad_(True)}
+    return weights
+
+
+@pytest.mark.parametrize('ns,sizes,gname,b', [([8, 4], [32, 32], 'g_mid', 50), ([25, 10], [32, 32], 'g_mid', 9),
+                                              ([4, 3, 2], [16, 8, 6], 'g_small', 7), ([3], [4], 'g_small', 5)])
+def test_model_embeddings_and_gradients_match_oracle(golden, cuda, ns, sizes, gname, b):
+    arrays, _ = golden
+    g = ga.Graph(*golden_graph_parts(arrays, gname))
+    e = arrays[gname + '_edges']
+    links = [(int(e[0, i]), int(e[1, i])) for i in range(b)]
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=4)
+    model = ga.GraphSAGE(sizes, gen, seed=9).build()
+    for p in model.parameters():                      # biases away from zero so they matter
+        if p.dim() == 1:
+            p.data.uniform_(-0.1, 0.1)
+    batch = gen.sample_features(links, 0)
+
+    plan = omodel.LayerPlan(sizes, ns, g.node_feature_sizes)
+    weights = _oracle_model(model, plan)
+    xin = [x.double() for x in map(torch.from_numpy, batch.numpy())]
+    want = omodel.forward(plan, weights, xin)
+
+    fused = model(batch)                              # ids -> gather-mean, deepest slots never materialised
+    dense = model([batch[i] for i in range(len(batch))])
+    assert len(fused) == 2 and tuple(fused[0].shape) == (b, sizes[-1])
+    for k in range(2):
+        close(fused[k], want[k], scale=1.0)
+        assert torch.equal(fused[k], dense[k])         # both paths sum in the same order
+
+    # gradients of a scalar loss through every kernel's backward
+    gen_t = torch.Generator().manual_seed(1)
+    cu, ci = torch.randn(b, sizes[-1], generator=gen_t, dtype=torch.float64), torch.randn(b, sizes[-1], generator=gen_t, dtype=torch.float64)
+    ((want[0] * cu).sum() + (want[1] * ci).sum()).backward()
+    ((fused[0] * cu.float().to(cuda)).sum() + (fused[1] * ci.float().to(cuda)).sum()).backward()
+    for (layer, node_type), w in weights.items():
+        agg = model._aggs[layer][node_type]
+        for name, p in (('w_self', agg.w_self), ('w_neigh', agg.w_neigh), ('bias', agg.bias)):
+            ref = w[name].grad
+            close(p.grad, ref, rtol=2e-5, scale=float(ref.abs().max()) + 1e-30)
+
+
+def test_aggregator_layer_call_convention(cuda):
+    gen = torch.Generator().manual_seed(3)
+    x_self = torch.randn(6, 4, 24, generator=gen)
+    x_neigh = torch.randn(6, 4, 8, 19, generator=gen)
+    agg = ga.Aggregator(32, seed=5)
+    out = agg([x_self.to(cuda), x_neigh.to(cuda)])
+    assert tuple(out.shape) == (6, 4, 32)
+    assert tuple(agg.w_self.shape) == (24, 16) and tuple(agg.w_neigh.shape) == (19, 16) and tuple(agg.bias.shape) == (32,)
+    assert float(agg.bias.abs().max()) == 0.0
+    limit = (6.0 / (24 + 16)) ** 0.5
+    assert float(agg.w_self.abs().max()) <= limit
+    want = omodel.aggregator(x_self.double(), x_neigh.double(), agg.w_self.detach().cpu().double(),
+                             agg.w_neigh.detach().cpu().double(), agg.bias.detach().cpu().double(), 'relu')
+    close(out, want)
+    with pytest.raises(NotImplementedError):
+        ga.Aggregator(32, agg_option='max')
