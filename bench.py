@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: seed edges/s of the 2-hop sample+aggregate forward pass.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg5|ml1m]
+
+A step = one batch of B seed edges through the hot path with every input already
+in HBM: sampler kernel (Philox draws) -> feature gathers and fused gather-mean ->
+per-type MFMA projections -> second layer -> l2-normalised user/item embeddings.
+N > 1 (launched by torch.distributed.run): the graph and features are replicated,
+rank r takes its own batches of seed edges, the forward pass needs no collective,
+and the reported value is the sum over ranks divided by the slowest rank's time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: users, items, undirected edges, Fu, Fi, fan-outs, layer sizes, item Zipf alpha, user alpha
+    'cfg2': dict(nu=1_000_000, ni=100_000, e=50_000_000, fu=64, fi=64, fan=[25, 10], layers=[32, 32],
+                 alpha_item=1.1, alpha_user=None,
+                 desc="synthetic bipartite 1M users x 100k items, 50M edges, 64-d features, 2-hop [25,10]"),
+    'cfg3': dict(nu=10_000_000, ni=1_000_000, e=500_000_000, fu=64, fi=64, fan=[25, 10], layers=[32, 32],
+                 alpha_item=1.3, alpha_user=1.3,
+                 desc="synthetic power-law bipartite 10M x 1M, 500M edges, 64-d features, 2-hop [25,10]"),
+    'cfg5': dict(nu=1_000_000, ni=100_000, e=50_000_000, fu=256, fi=256, fan=[25, 10, 5], layers=[256, 256, 256],
+                 alpha_item=1.1, alpha_user=None,
+                 desc="cfg2 graph, 3-hop [25,10,5], 256-d features, 256 hidden"),
+    'ml1m': dict(nu=6040, ni=3706, e=226_310, fu=24, fi=19, fan=[10, 5], layers=[32, 32],
+                 alpha_item=0.9, alpha_user=None,
+                 desc="MovieLens-1M-shaped synthetic 6040 x 3706, 226k edges, 2-hop [10,5]"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=4096, help='seed edges per step per GPU')
+    ap.add_argument('--seed-pool', type=int, default=1 << 20, help='seed edges drawn from the first N edges')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batches', type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(graph, cfg, heads_u, heads_i, model, n_batches, batch=100):
+    """The oracle (a port of the reference's Python path) on the host: flow()
+    batch build (walk + regroup + feature gather) and the float32 model forward,
+    one thread, on ``n_batches`` batches of the reference's own batch size."""
+    import random
+    import numpy as np
+    import torch
+    from oracle import generator as ogen
+    from oracle import model as omodel
+    from oracle.graph import OracleGraph
+
+    dev = graph.device_tensors()
+    feats = {'user': dev['user'].cpu().numpy(), 'item': dev['item'].cpu().numpy()}
+    og = OracleGraph.from_csr(feats, graph.num_users, graph.num_items,
+                              dev['indptr'].cpu().numpy(), dev['indices'].cpu().numpy())
+    hu, hi = heads_u[:n_batches * batch].cpu().numpy(), heads_i[:n_batches * batch].cpu().numpy()
+    links = [(int(a), int(b)) for a, b in zip(hu, hi)]
+    plan = omodel.LayerPlan(cfg['layers'], cfg['fan'], og.node_feature_sizes)
+    weights = {(l, t): {'w_self': a.w_self.detach().cpu(), 'w_neigh': a.w_neigh.detach().cpu(),
+                        'bias': a.bias.detach().cpu()}
+               for l, aggs in enumerate(model._aggs) for t, a in aggs.items()}
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+
+    def one_pass():
+        random.seed(12345)
+        t0 = time.perf_counter()
+        for k in range(n_batches):
+            xs = ogen.sample_features_faithful(og, cfg['fan'], links[k * batch:(k + 1) * batch], random)
+            omodel.forward(plan, weights, [torch.from_numpy(np.ascontiguousarray(x)) for x in xs])
+        return time.perf_counter() - t0
+
+    one_pass()                       # fills the neighbor-list cache (the reference holds plain lists)
+    dt = one_pass()
+    torch.set_num_threads(threads)
+    return {"value": n_batches * batch / dt, "unit": "seed edges/s", "cores": 1, "kind": "port",
+            "sample": "%d batches x %d seed edges (the reference script's batch size), same graph and fan-outs; "
+                      "flow() batch build + fp32 forward, single thread, %.1f s" % (n_batches, batch, dt),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+
+    import graphsage_amd as ga
+    from graphsage_amd import synthetic
+    from graphsage_amd.engine import SageForwardEngine
+
+    cfg = WORKLOADS[args.workload]
+    b = args.batch
+    graph, u, it = synthetic.power_law_bipartite(cfg['nu'], cfg['ni'], cfg['e'], cfg['fu'], cfg['fi'],
+                                                 alpha_item=cfg['alpha_item'], alpha_user=cfg['alpha_user'],
+                                                 seed=1234, device=device)
+    heads_u, heads_i = synthetic.seed_edges(u, it, args.seed_pool, seed=0)
+    del u, it
+    gen = ga.GraphSAGEGenerator(graph, b, cfg['fan'], head_node_types=['user', 'item'], seed=0x9E3779B97F4A7C15)
+    model = ga.GraphSAGE(cfg['layers'], gen, seed=7).build()
+    engine = SageForwardEngine(graph, model, b)
+
+    # per-step inputs, resident in HBM: roots (sources then destinations) and the walk ids
+    # 2*edge + side that key the draws independently of how edges are split over ranks
+    n_batches = heads_u.numel() // b
+    edge_ids = torch.arange(n_batches * b, dtype=torch.int64, device=device).reshape(n_batches, b)
+    seeds = torch.cat([heads_u[:n_batches * b].reshape(n_batches, b),
+                       heads_i[:n_batches * b].reshape(n_batches, b)], dim=1).contiguous()
+    walk_ids = torch.cat([2 * edge_ids, 2 * edge_ids + 1], dim=1).contiguous()
+    my_batches = list(range(rank, n_batches, world))
+
+    def step(i):
+        k = my_batches[i % len(my_batches)]
+        return engine.forward(seeds[k], walk_ids[k], rng_seed=gen.sampler.seed)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    probes = []
+    engine.probes = probes
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    engine.probes = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    err = engine.err_flag.tolist()
+    assert err == [0, 0], "sampler reported %s" % err
+
+    if rank == 0:
+        total_edges = args.steps * b * world
+        value = total_edges / elapsed
+        samp_bytes, agg_bytes = engine.algorithmic_bytes()
+        dom_ms = [a.elapsed_time(c) for a, c in probes]
+        dom_avg = sum(dom_ms) / max(len(dom_ms), 1) * 1e-3
+        dom_bytes = engine.dominant_bytes()
+        achieved = dom_bytes / dom_avg / 1e9 if dom_avg > 0 else 0.0
+        out = {
+            "metric": "seed edges/sec (2-hop sample+aggregate fwd)" if len(cfg['fan']) == 2
+                      else "seed edges/sec (%d-hop sample+aggregate fwd)" % len(cfg['fan']),
+            "value": value, "unit": "seed edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, cfg['desc']), "batch_per_gpu": b,
+                       "layer_sizes": cfg['layers'], "rng": "philox4x32-10",
+                       "parallelism": "seed-edge data parallel x%d, graph+features replicated" % world},
+            "algorithmic_bytes_per_seed_edge": (samp_bytes + agg_bytes) / b,
+            "achieved_hbm_gbps_whole_step": (samp_bytes + agg_bytes) / b * value / world / 1e9,
+            "roofline": {"bound": "hbm", "kernel": engine.dominant_name(), "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": engine.measured_traffic(),
+                         "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(graph, cfg, heads_u, heads_i, model, args.cpu_batches)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -161,9 +161,9 @@ inline unsigned grid_for(int64_t items, int per_block, int64_t cap = 1 << 20) {
 
 extern "C" int gs_gather_rows(const float *feat, int64_t n_rows, int F, int64_t id_offset,
                               const int32_t *ids, int64_t n, float *out, void *stream) {
+    if (n == 0) return GS_OK;
     if (!feat || !ids || !out) return gs::fail(GS_EINVAL, "gs_gather_rows: null pointer argument");
     if (F < 1 || n < 0 || n_rows < 0) return gs::fail(GS_EINVAL, "gs_gather_rows: F=%d n=%lld n_rows=%lld", F, (long long)n, (long long)n_rows);
-    if (n == 0) return GS_OK;
     const int vec = pick_vec(F, feat, out);
     const int lg = group_log2(F, vec);
     const int groups = kThreads >> lg;
@@ -178,12 +178,12 @@ extern "C" int gs_gather_rows(const float *feat, int64_t n_rows, int F, int64_t 
 extern "C" int gs_gather_mean_fwd(const float *feat, int64_t n_rows, int F, int64_t id_offset,
                                   const int32_t *child_ids, int64_t n_parents, int n_child,
                                   float *out_mean, void *stream) {
+    if (n_parents == 0) return GS_OK;
     if (!feat || !out_mean) return gs::fail(GS_EINVAL, "gs_gather_mean_fwd: null pointer argument");
     if (F < 1 || n_child < 1 || n_parents < 0 || n_rows < 0)
         return gs::fail(GS_EINVAL, "gs_gather_mean_fwd: F=%d n_child=%d n_parents=%lld n_rows=%lld", F, n_child, (long long)n_parents, (long long)n_rows);
     if (!child_ids && n_parents * (int64_t)n_child > n_rows)
         return gs::fail(GS_EINVAL, "gs_gather_mean_fwd: dense groups need n_parents*n_child <= n_rows");
-    if (n_parents == 0) return GS_OK;
     const int vec = pick_vec(F, feat, out_mean);
     const int lg = group_log2(F, vec);
     const int groups = kThreads >> lg;
@@ -203,12 +203,12 @@ extern "C" int gs_gather_mean_fwd(const float *feat, int64_t n_rows, int F, int6
 extern "C" int gs_gather_mean_bwd(const float *g_mean, const int32_t *child_ids, int64_t n_parents,
                                   int n_child, int F, int64_t id_offset, int64_t n_rows,
                                   float *g_feat, void *stream) {
+    if (n_parents == 0) return GS_OK;
     if (!g_mean || !g_feat) return gs::fail(GS_EINVAL, "gs_gather_mean_bwd: null pointer argument");
     if (F < 1 || n_child < 1 || n_parents < 0 || n_rows < 0)
         return gs::fail(GS_EINVAL, "gs_gather_mean_bwd: F=%d n_child=%d n_parents=%lld n_rows=%lld", F, n_child, (long long)n_parents, (long long)n_rows);
     if (!child_ids && n_parents * (int64_t)n_child > n_rows)
         return gs::fail(GS_EINVAL, "gs_gather_mean_bwd: dense groups need n_parents*n_child <= n_rows");
-    if (n_parents == 0) return GS_OK;
     const int vec = pick_vec(F, g_mean, g_feat);
     const int lg = group_log2(F, vec);
     const int groups = kThreads >> lg;

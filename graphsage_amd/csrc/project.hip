@@ -327,10 +327,10 @@ inline void wgrad_chunks(int64_t M, int64_t *rows_per_chunk, int64_t *n_chunks) 
 extern "C" int gs_sage_project_fwd(const float *x_self, int Fs, const float *x_mean, int Fn, int64_t M,
                                    const float *W_self, const float *W_neigh, const float *bias,
                                    int H, int act, float *out, void *stream) {
-    if (!x_self || !x_mean || !W_self || !W_neigh || !out)
-        return gs::fail(GS_EINVAL, "gs_sage_project_fwd: null pointer argument");
     if (int rc = check_project_shape("gs_sage_project_fwd", Fs, Fn, M, H, act)) return rc;
     if (M == 0) return GS_OK;
+    if (!x_self || !x_mean || !W_self || !W_neigh || !out)
+        return gs::fail(GS_EINVAL, "gs_sage_project_fwd: null pointer argument");
     const int Hh = H / 2;
     GemmSide s0{}, s1{};
     s0.A = x_self; s0.B = W_self; s0.bias = bias; s0.out = out;
@@ -360,10 +360,10 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
                                    float *g_W_self, float *g_W_neigh, float *g_bias,
                                    float *g_x_self, float *g_x_mean,
                                    void *workspace, size_t workspace_bytes, void *stream) {
-    if (!x_self || !x_mean || !W_self || !W_neigh || !g_out)
-        return gs::fail(GS_EINVAL, "gs_sage_project_bwd: null pointer argument");
     if (int rc = check_project_shape("gs_sage_project_bwd", Fs, Fn, M, H, act)) return rc;
-    if (act == GS_ACT_RELU && !out) return gs::fail(GS_EINVAL, "gs_sage_project_bwd: relu needs the forward output");
+    if (M > 0 && (!x_self || !x_mean || !W_self || !W_neigh || !g_out))
+        return gs::fail(GS_EINVAL, "gs_sage_project_bwd: null pointer argument");
+    if (M > 0 && act == GS_ACT_RELU && !out) return gs::fail(GS_EINVAL, "gs_sage_project_bwd: relu needs the forward output");
     const int Hh = H / 2;
     hipStream_t s = (hipStream_t)stream;
     const float *mask = act == GS_ACT_RELU ? out : nullptr;
@@ -417,9 +417,9 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
 }
 
 extern "C" int gs_l2_normalize_fwd(const float *x, int64_t M, int H, float *out, void *stream) {
-    if (!x || !out) return gs::fail(GS_EINVAL, "gs_l2_normalize_fwd: null pointer argument");
     if (H < 1 || M < 0) return gs::fail(GS_EINVAL, "gs_l2_normalize_fwd: M=%lld H=%d", (long long)M, H);
     if (M == 0) return GS_OK;
+    if (!x || !out) return gs::fail(GS_EINVAL, "gs_l2_normalize_fwd: null pointer argument");
     int64_t blocks = (M + 3) / 4;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, x, M, H, out);
@@ -427,9 +427,9 @@ extern "C" int gs_l2_normalize_fwd(const float *x, int64_t M, int H, float *out,
 }
 
 extern "C" int gs_l2_normalize_bwd(const float *x, const float *g_out, int64_t M, int H, float *g_x, void *stream) {
-    if (!x || !g_out || !g_x) return gs::fail(GS_EINVAL, "gs_l2_normalize_bwd: null pointer argument");
     if (H < 1 || M < 0) return gs::fail(GS_EINVAL, "gs_l2_normalize_bwd: M=%lld H=%d", (long long)M, H);
     if (M == 0) return GS_OK;
+    if (!x || !g_out || !g_x) return gs::fail(GS_EINVAL, "gs_l2_normalize_bwd: null pointer argument");
     int64_t blocks = (M + 3) / 4;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, x, g_out, M, H, g_x);

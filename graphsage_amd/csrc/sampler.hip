@@ -89,6 +89,7 @@ extern "C" int gs_sample(const int64_t *indptr, const int32_t *indices, int64_t 
                          uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
                          const uint32_t *replay,
                          int32_t *const *out_hops, int32_t *err_flag, void *stream) {
+    if (n_seeds == 0) return GS_OK;                 // empty batch: pointers may be null
     if (!indptr || !indices || !seeds || !fanouts || !out_hops || !err_flag)
         return gs::fail(GS_EINVAL, "gs_sample: null pointer argument");
     if (n_hops < 1 || n_hops > GS_MAX_HOPS)
@@ -96,8 +97,6 @@ extern "C" int gs_sample(const int64_t *indptr, const int32_t *indices, int64_t 
     if (n_seeds < 0 || n_nodes <= 0 || n_nodes > 0x7FFFFFFELL)
         return gs::fail(GS_EINVAL, "gs_sample: n_seeds=%lld n_nodes=%lld out of range",
                         (long long)n_seeds, (long long)n_nodes);
-    if (n_seeds == 0) return GS_OK;
-
     SampleParams P{};
     P.n_hops = n_hops;
     int64_t prod = 1, off = 0;

@@ -1,0 +1,192 @@
+"""Static launch plan for the forward hot path (sample -> aggregate -> embed).
+
+``GraphSAGE.__call__`` mirrors the reference layer by layer and allocates as it
+goes; this engine is the same arithmetic laid out once for a fixed batch size:
+all buffers are allocated up front, slots of one node type share a buffer so a
+layer is ONE projection launch per type, and a step is a fixed list of kernel
+launches on the current stream with no host synchronisation (it can be captured
+in a HIP graph).  It is what the benchmark times and what inference uses.
+
+Buffer layout.  Slot ``s = 2*h + side`` (hop ``h`` of the walks rooted at head
+``side``) has ``B * P_h`` nodes of type ``TYPES[(side + h) % 2]``.  Per node
+type ``T`` the head rows of all alive slots of that type are stored back to
+back in slot order: ``x_self[T]`` (own features), ``x_mean[T]`` (mean of the
+sampled neighbors' features, which are of the other type) and the layer outputs
+``h[l][T]``.  Slots die from the deepest hop upwards as layers are applied, so
+the rows alive at layer ``l`` are always a prefix of the buffer.
+"""
+import torch
+
+from . import kernels
+
+_TYPES = ('user', 'item')
+
+
+class SageForwardEngine:
+    def __init__(self, graph, model, batch_size):
+        self.graph = graph
+        self.model = model.build()
+        self.fanouts = [int(n) for n in model.n_samples]
+        self.n_hops = len(self.fanouts)
+        self.batch = int(batch_size)
+        dev = graph.device_tensors()
+        self.tables = {'user': (dev['user'], 0), 'item': (dev['item'], graph.correction_constant)}
+        self.indptr, self.indices = dev['indptr'], dev['indices']
+        device = self.indptr.device
+        b = self.batch
+        sizes = [1] + kernels.hop_sizes(self.fanouts)              # nodes per head at hop h
+        self.sizes = sizes
+
+        # segments: for each type, [(slot, hop, side, first_row, n_rows)] over hops 0..L-1
+        self.segments = {t: [] for t in _TYPES}
+        rows = {t: 0 for t in _TYPES}
+        self.where = {}
+        for h in range(self.n_hops):
+            for side in range(2):
+                t = _TYPES[(side + h) % 2]
+                n = b * sizes[h]
+                self.segments[t].append((2 * h + side, h, side, rows[t], n))
+                self.where[2 * h + side] = (t, rows[t], n)
+                rows[t] += n
+        self.rows = rows
+        f = graph.node_feature_sizes
+        other = {'user': 'item', 'item': 'user'}
+        self.other = other
+        new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=device)
+        self.x_self = {t: new(rows[t], f[t]) for t in _TYPES}
+        self.x_mean = [{t: new(rows[t], model.dims[0][other[t]]) for t in _TYPES}]
+        self.h = []
+        for layer in range(self.n_hops):
+            alive = {t: sum(n for (_, hh, _, _, n) in self.segments[t] if hh <= self.n_hops - 1 - layer) for t in _TYPES}
+            self.h.append({t: new(alive[t], model.dims[layer + 1][t]) for t in _TYPES})
+            if layer + 1 < self.n_hops:
+                nxt = {t: sum(n for (_, hh, _, _, n) in self.segments[t] if hh <= self.n_hops - 2 - layer) for t in _TYPES}
+                self.x_mean.append({t: new(nxt[t], model.dims[layer + 1][other[t]]) for t in _TYPES})
+        self.emb = {t: new(b, model.dims[-1][t]) for t in _TYPES}
+        self.hops = [torch.empty((2 * b, s), dtype=torch.int32, device=device) for s in sizes[1:]]
+        self.err_flag = torch.zeros(2, dtype=torch.int32, device=device)
+        self._hop_ptrs = None
+        self.probes = None           # list to receive (start, end) events around the dominant launches
+
+    # -- pieces ---------------------------------------------------------------
+    def _slot_ids(self, seeds, h, side):
+        b = self.batch
+        src = seeds if h == 0 else self.hops[h - 1]
+        return src[side * b:(side + 1) * b].reshape(-1)
+
+    def sample(self, seeds, walk_ids=None, rng_seed=0, replay=None):
+        import ctypes
+        from ._lib import check, load, ptr, stream_handle
+        lib = load()
+        if self._hop_ptrs is None:
+            self._fan_arr = (ctypes.c_int32 * self.n_hops)(*self.fanouts)
+            self._hop_ptrs = (ctypes.c_void_p * self.n_hops)(*[t.data_ptr() for t in self.hops])
+        if seeds.numel() != 2 * self.batch or seeds.dtype != torch.int32 or not seeds.is_cuda:
+            raise ValueError("seeds must be an int32 GPU tensor of 2*batch roots (sources, then destinations)")
+        if walk_ids is not None and (walk_ids.numel() != seeds.numel() or walk_ids.dtype != torch.int64):
+            raise ValueError("walk_ids must be int64, one per seed")
+        if replay is not None and replay.numel() != seeds.numel() * sum(self.sizes[1:]):
+            raise ValueError("replay tape has the wrong length")
+        check(lib.gs_sample(ptr(self.indptr), ptr(self.indices), self.indptr.numel() - 1, ptr(seeds),
+                            seeds.numel(), self._fan_arr, self.n_hops, int(rng_seed) & 0xFFFFFFFFFFFFFFFF, 0,
+                            ptr(walk_ids), ptr(replay), self._hop_ptrs, ptr(self.err_flag), stream_handle()),
+              'gs_sample')
+
+    def aggregate(self, seeds):
+        """Layers 0..L-1 on the ids left by ``sample``; returns (user_emb, item_emb)."""
+        m = self.model
+        other = self.other
+        # layer 0: own rows of every alive slot, then neighbor means
+        for t in _TYPES:
+            feat, off = self.tables[t]
+            for (_, h, side, r0, n) in self.segments[t]:
+                kernels.gather_rows(feat, self._slot_ids(seeds, h, side), off, out=self.x_self[t][r0:r0 + n])
+        for t in _TYPES:
+            for (s, h, side, r0, n) in self.segments[t]:
+                dst = self.x_mean[0][t][r0:r0 + n]
+                if h + 1 < self.n_hops:
+                    _, c0, cn = self.where[s + 2]
+                    kernels.gather_mean(self.x_self[other[t]][c0:c0 + cn], None, n, self.fanouts[h], out=dst)
+                else:
+                    feat, off = self.tables[other[t]]
+                    if self.probes is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    kernels.gather_mean(feat, self._slot_ids(seeds, h + 1, side), n, self.fanouts[h], off, out=dst)
+                    if self.probes is not None:
+                        e1.record()
+                        self.probes.append((e0, e1))
+        for layer in range(self.n_hops):
+            if layer > 0:
+                for t in _TYPES:
+                    for (s, h, side, r0, n) in self.segments[t]:
+                        if h > self.n_hops - 1 - layer:
+                            continue
+                        _, c0, cn = self.where[s + 2]
+                        kernels.gather_mean(self.h[layer - 1][other[t]][c0:c0 + cn], None, n, self.fanouts[h],
+                                            out=self.x_mean[layer][t][r0:r0 + n])
+            for t in _TYPES:
+                agg = m._aggs[layer][t]
+                rows = self.h[layer][t].shape[0]
+                x_self = self.x_self[t] if layer == 0 else self.h[layer - 1][t]
+                kernels.sage_project(x_self[:rows], self.x_mean[layer][t][:rows], agg.w_self, agg.w_neigh,
+                                     agg.bias, agg.activation, out=self.h[layer][t])
+        for t in _TYPES:
+            if m.normalize == "l2":
+                kernels.l2_normalize(self.h[-1][t], out=self.emb[t])
+            else:
+                self.emb[t].copy_(self.h[-1][t])
+        return self.emb['user'], self.emb['item']
+
+    def forward(self, seeds, walk_ids=None, rng_seed=0, replay=None):
+        self.sample(seeds, walk_ids, rng_seed, replay)
+        return self.aggregate(seeds)
+
+    # -- accounting for the benchmark --------------------------------------------
+    def dominant_name(self):
+        return "gather_mean_kernel (deepest hop: rows summed as fetched)"
+
+    def dominant_bytes(self):
+        """Algorithmic bytes of ONE launch of the deepest-hop gather-mean: child
+        ids read, one feature row read per child, one mean row written per
+        parent (average of the user-table and item-table launches)."""
+        b, h = self.batch, self.n_hops - 1
+        f = self.graph.node_feature_sizes
+        parents, children = b * self.sizes[h], b * self.sizes[h + 1]
+        per_type = [children * 4 + children * f[t] * 4 + parents * f[t] * 4 for t in _TYPES]
+        return sum(per_type) / len(per_type)
+
+    def measured_traffic(self):
+        """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes,
+        if a measurement for this build was stored under profiles/."""
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'traffic.json')
+        if not os.path.exists(path):
+            return None
+        with open(path) as fh:
+            rec = json.load(fh)
+        key = "gather_mean_kernel/B%d/%s" % (self.batch, 'x'.join(str(n) for n in self.fanouts))
+        return rec.get(key)
+
+    # algorithmic bytes of one step, per the accounting used for the roofline
+    def algorithmic_bytes(self):
+        """(sampler bytes, gather+aggregate bytes) one batch must move at least:
+        ids and CSR row bounds read, sampled ids written; every sampled node's
+        feature row read once and the layer-0 inputs (own row + neighbor mean
+        per head node) written once."""
+        b = self.batch
+        f = self.graph.node_feature_sizes
+        sizes = self.sizes
+        expansions = 2 * sum(sizes[h] for h in range(self.n_hops))
+        samples = 2 * sum(sizes[h] for h in range(1, self.n_hops + 1))
+        sampler = b * (8 + 16 * expansions + 4 * samples + 4 * samples)
+        rows_read = 0
+        written = 0
+        for h in range(self.n_hops + 1):
+            for side in range(2):
+                t = _TYPES[(side + h) % 2]
+                rows_read += b * sizes[h] * f[t] * 4
+                if h < self.n_hops:
+                    written += b * sizes[h] * (f[t] + f[self.other[t]]) * 4
+        return sampler, rows_read + written
