@@ -35,6 +35,19 @@ SIGNATURES = {
     'gs_l2_normalize_bwd': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
 }
 
+
+
+class FusedSegment(_c.Structure):
+    """gs_fused_segment of include/gsage.h."""
+    _fields_ = [('head_ids', _vp), ('child_ids', _vp), ('n_heads', _i64), ('self_row0', _i64),
+                ('child_row0', _i64), ('n_child', _c.c_int32)]
+
+
+SIGNATURES['gs_sage_fused_supported'] = (_i32, [_i32, _i32, _i32, _i32])
+SIGNATURES['gs_sage_fused_fwd'] = (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i64,
+                                          _c.POINTER(FusedSegment), _i32, _vp, _vp, _vp, _i32, _i32, _i32,
+                                          _vp, _vp, _vp, _vp])
+
 _lib = None
 
 

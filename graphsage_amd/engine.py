@@ -23,7 +23,7 @@ _TYPES = ('user', 'item')
 
 
 class SageForwardEngine:
-    def __init__(self, graph, model, batch_size):
+    def __init__(self, graph, model, batch_size, use_fused=True):
         self.graph = graph
         self.model = model.build()
         self.fanouts = [int(n) for n in model.n_samples]
@@ -67,6 +67,13 @@ class SageForwardEngine:
         self.err_flag = torch.zeros(2, dtype=torch.int32, device=device)
         self._hop_ptrs = None
         self.probes = None           # list to receive (start, end) events around the dominant launches
+        # static inputs: a step copies its roots / walk ids here, so every launch of the plan
+        # sees fixed addresses (prepared argument lists, HIP-graph capture)
+        self.seeds_buf = torch.zeros(2 * b, dtype=torch.int32, device=device)
+        self.walk_buf = torch.zeros(2 * b, dtype=torch.int64, device=device)
+        self.use_fused = use_fused
+        self.fused_layers = [self._fused_ok(layer) and use_fused for layer in range(self.n_hops)]
+        self._fused_calls = {}
 
     # -- pieces ---------------------------------------------------------------
     def _slot_ids(self, seeds, h, side):
@@ -138,12 +145,81 @@ class SageForwardEngine:
                 self.emb[t].copy_(self.h[-1][t])
         return self.emb['user'], self.emb['item']
 
+    # -- fused layers ----------------------------------------------------------------
+    def _fused_ok(self, layer):
+        m = self.model
+        for t in _TYPES:
+            fs, fn, h = m.dims[layer][t], m.dims[layer][self.other[t]], m.dims[layer + 1][t]
+            if not kernels.fused_supported(fs, fn, h, max(self.fanouts)):
+                return False
+        return True
+
+    def _fused_call(self, layer, t):
+        """Prepared one-kernel layer for head type ``t`` (built on first use)."""
+        key = (layer, t)
+        if key in self._fused_calls:
+            return self._fused_calls[key]
+        m, other = self.model, self.other
+        agg = m._aggs[layer][t]
+        last = layer == self.n_hops - 1
+        segs = []
+        for (s, h, side, r0, n) in self.segments[t]:
+            if h > self.n_hops - 1 - layer:
+                continue
+            if layer == 0:
+                segs.append({'head_ids': self._slot_ids(self.seeds_buf, h, side),
+                             'child_ids': self._slot_ids(self.seeds_buf, h + 1, side),
+                             'n_heads': n, 'n_child': self.fanouts[h]})
+            else:
+                _, c0, _cn = self.where[s + 2]
+                segs.append({'n_heads': n, 'n_child': self.fanouts[h], 'self_row0': r0, 'child_row0': c0})
+        if layer == 0:
+            (f_self, o_self), (f_neigh, o_neigh) = self.tables[t], self.tables[other[t]]
+        else:
+            f_self, o_self, f_neigh, o_neigh = self.h[layer - 1][t], 0, self.h[layer - 1][other[t]], 0
+        normalize = last and m.normalize == "l2"
+        out = self.emb[t] if last else self.h[layer][t]
+        call = kernels.FusedLayerCall(f_self, o_self, f_neigh, o_neigh, segs, agg.w_self, agg.w_neigh, agg.bias,
+                                      agg.activation, normalize, out)
+        self._fused_calls[key] = call
+        return call
+
+    def _run_fused_layer(self, layer):
+        for t in _TYPES:
+            call = self._fused_call(layer, t)
+            if self.probes is not None and layer == 0:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                call.run()
+                e1.record()
+                self.probes.append((e0, e1))
+            else:
+                call.run()
+
+    def aggregate_fused(self):
+        """Same result as ``aggregate`` with one kernel per (layer, node type) for
+        the layers the fused kernel covers; ids come from ``seeds_buf``/``hops``."""
+        if not all(self.fused_layers):
+            return self.aggregate(self.seeds_buf)
+        for layer in range(self.n_hops):
+            self._run_fused_layer(layer)
+        if self.model.normalize != "l2":
+            pass                                     # emb already holds the last layer's output
+        return self.emb['user'], self.emb['item']
+
     def forward(self, seeds, walk_ids=None, rng_seed=0, replay=None):
-        self.sample(seeds, walk_ids, rng_seed, replay)
-        return self.aggregate(seeds)
+        self.seeds_buf.copy_(seeds)
+        if walk_ids is not None:
+            self.walk_buf.copy_(walk_ids)
+        self.sample(self.seeds_buf, self.walk_buf if walk_ids is not None else None, rng_seed, replay)
+        if self.use_fused and all(self.fused_layers):
+            return self.aggregate_fused()
+        return self.aggregate(self.seeds_buf)
 
     # -- accounting for the benchmark --------------------------------------------
     def dominant_name(self):
+        if self.use_fused and all(self.fused_layers):
+            return "sage_fused_kernel (layer 0: gather + neighbor mean + projection, one launch per node type)"
         return "gather_mean_kernel (deepest hop: rows summed as fetched)"
 
     def dominant_bytes(self):
@@ -152,6 +228,18 @@ class SageForwardEngine:
         parent (average of the user-table and item-table launches)."""
         b, h = self.batch, self.n_hops - 1
         f = self.graph.node_feature_sizes
+        if self.use_fused and all(self.fused_layers):
+            # fused layer 0, one launch per head type: head + child ids read, one feature row per
+            # head and per child read, one output row per head written
+            per_type = []
+            for t in _TYPES:
+                tot = 0
+                for (_, hh, _, _, n) in self.segments[t]:
+                    kids = n * self.fanouts[hh]
+                    tot += (n + kids) * 4 + n * f[t] * 4 + kids * f[self.other[t]] * 4
+                    tot += n * self.model.dims[1][t] * 4
+                per_type.append(tot)
+            return sum(per_type) / len(per_type)
         parents, children = b * self.sizes[h], b * self.sizes[h + 1]
         per_type = [children * 4 + children * f[t] * 4 + parents * f[t] * 4 for t in _TYPES]
         return sum(per_type) / len(per_type)
@@ -166,7 +254,8 @@ class SageForwardEngine:
             return None
         with open(path) as fh:
             rec = json.load(fh)
-        key = "gather_mean_kernel/B%d/%s" % (self.batch, 'x'.join(str(n) for n in self.fanouts))
+        name = "sage_fused_kernel" if self.use_fused and all(self.fused_layers) else "gather_mean_kernel"
+        key = "%s/B%d/%s" % (name, self.batch, 'x'.join(str(n) for n in self.fanouts))
         return rec.get(key)
 
     # algorithmic bytes of one step, per the accounting used for the roofline

@@ -207,3 +207,78 @@ def l2_normalize_bwd(x, g_out):
     check(lib.gs_l2_normalize_bwd(ptr(x), ptr(g_out), x.shape[0], x.shape[1], ptr(g_x), stream_handle()),
           'gs_l2_normalize_bwd')
     return g_x
+
+
+def fused_supported(fs, fn, h, max_child):
+    return bool(load().gs_sage_fused_supported(int(fs), int(fn), int(h), int(max_child)))
+
+
+class FusedLayerCall:
+    """A prepared ``gs_sage_fused_fwd`` call: segment table and argument checks
+    are done once, ``run()`` only enqueues the kernel."""
+
+    def __init__(self, feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_neigh, bias, act,
+                 normalize, out, save_self=None, save_mean=None):
+        lib = load()
+        _dev(feat_self, torch.float32, 'feat_self', 2)
+        _dev(feat_neigh, torch.float32, 'feat_neigh', 2)
+        _dev(w_self, torch.float32, 'w_self', 2)
+        _dev(w_neigh, torch.float32, 'w_neigh', 2)
+        _dev(out, torch.float32, 'out', 2)
+        fs, fn, hh = feat_self.shape[1], feat_neigh.shape[1], w_self.shape[1]
+        if tuple(w_self.shape) != (fs, hh) or tuple(w_neigh.shape) != (fn, hh):
+            raise ValueError("weight shapes do not match the feature widths")
+        if bias is not None:
+            _dev(bias, torch.float32, 'bias', 1)
+            if bias.numel() != 2 * hh:
+                raise ValueError("bias must have %d entries" % (2 * hh))
+        rows = 0
+        self._keep = []
+        arr = (_lib.FusedSegment * len(segments))()
+        for i, sg in enumerate(segments):
+            n_heads, n_child = int(sg['n_heads']), int(sg['n_child'])
+            head_ids, child_ids = sg.get('head_ids'), sg.get('child_ids')
+            if head_ids is not None:
+                _dev(head_ids, torch.int32, 'head_ids')
+                if head_ids.numel() != n_heads:
+                    raise ValueError("segment %d: head_ids has %d entries, %d needed" % (i, head_ids.numel(), n_heads))
+            if child_ids is not None:
+                _dev(child_ids, torch.int32, 'child_ids')
+                if child_ids.numel() != n_heads * n_child:
+                    raise ValueError("segment %d: child_ids has %d entries, %d needed" %
+                                     (i, child_ids.numel(), n_heads * n_child))
+            arr[i] = _lib.FusedSegment(ptr(head_ids), ptr(child_ids), n_heads, int(sg.get('self_row0', 0)),
+                                       int(sg.get('child_row0', 0)), n_child)
+            self._keep += [head_ids, child_ids]
+            rows += n_heads
+        if tuple(out.shape) != (rows, 2 * hh):
+            raise ValueError("out must be (%d, %d)" % (rows, 2 * hh))
+        for name, t, width in (('save_self', save_self, fs), ('save_mean', save_mean, fn)):
+            if t is not None:
+                _dev(t, torch.float32, name, 2)
+                if tuple(t.shape) != (rows, width):
+                    raise ValueError("%s must be (%d, %d)" % (name, rows, width))
+        max_child = max([int(sg['n_child']) for sg in segments] or [1])
+        if not lib.gs_sage_fused_supported(fs, fn, 2 * hh, max_child):
+            raise _lib.GsageError("fused layer kernel does not cover Fs=%d Fn=%d H=%d n_child=%d" %
+                                  (fs, fn, 2 * hh, max_child))
+        self._lib = lib
+        self._keep += [feat_self, feat_neigh, w_self, w_neigh, bias, out, save_self, save_mean]
+        self._args = (ptr(feat_self), feat_self.shape[0], fs, int(off_self), ptr(feat_neigh), feat_neigh.shape[0],
+                      fn, int(off_neigh), arr, len(segments), ptr(w_self), ptr(w_neigh), ptr(bias), 2 * hh,
+                      ACT[act], int(bool(normalize)), ptr(out), ptr(save_self), ptr(save_mean))
+        self.out = out
+
+    def run(self):
+        check(self._lib.gs_sage_fused_fwd(*self._args, stream_handle()), 'gs_sage_fused_fwd')
+        return self.out
+
+
+def sage_fused(feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_neigh, bias, act,
+               normalize=False, out=None, save_self=None, save_mean=None):
+    """One aggregator layer in one kernel; see include/gsage.h: gs_sage_fused_fwd."""
+    rows = sum(int(sg['n_heads']) for sg in segments)
+    if out is None:
+        out = torch.empty((rows, 2 * w_self.shape[1]), dtype=torch.float32, device=feat_self.device)
+    return FusedLayerCall(feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_neigh, bias, act,
+                          normalize, out, save_self, save_mean).run()

@@ -147,6 +147,45 @@ int gs_l2_normalize_fwd(const float *x, int64_t M, int H, float *out, void *stre
 int gs_l2_normalize_bwd(const float *x, const float *g_out, int64_t M, int H,
                         float *g_x, void *stream);
 
+/*
+ * One whole aggregator layer in a single kernel:
+ *   out[p, :] = act(concat(self[p] @ W_self, mean_j(child[p, j]) @ W_neigh) + bias)
+ * (optionally followed by the row l2 normalisation), i.e. gs_gather_rows +
+ * gs_gather_mean_fwd + gs_sage_project_fwd (+ gs_l2_normalize_fwd) without
+ * writing their intermediates: Aggregator.call (utils.py:103-120) applied to
+ * rows that are fetched by node id (generator.py:270-277, bipartite_graph.py:
+ * 70-76), and models.py:186-190 for the normalisation.
+ *
+ * The head nodes are given as up to 2*GS_MAX_HOPS segments (HOST array) that all
+ * use the same feature tables and weights (the slots of one node type in one
+ * layer, models.py:79-90); output rows follow segment order.
+ *   head_ids  device node ids of the segment's heads, or NULL: head p is row
+ *             self_row0 + p of feat_self (layer >= 1: inputs are activations)
+ *   child_ids device node ids [n_heads * n_child] of the sampled neighbors, or
+ *             NULL: child j of head p is row child_row0 + p*n_child + j of
+ *             feat_neigh
+ * save_self / save_mean: optional device [rows, Fs] / [rows, Fn] copies of the
+ * gathered own rows and neighbor means (what the backward pass needs).
+ * Supported shapes: gs_sage_fused_supported(Fs, Fn, H, max n_child) != 0;
+ * otherwise GS_ELIMIT is returned and the three separate entry points apply.
+ */
+typedef struct gs_fused_segment {
+    const int32_t *head_ids;
+    const int32_t *child_ids;
+    int64_t n_heads;
+    int64_t self_row0;
+    int64_t child_row0;
+    int32_t n_child;
+} gs_fused_segment;
+
+int gs_sage_fused_supported(int Fs, int Fn, int H, int max_child);
+int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
+                      const float *feat_neigh, int64_t n_rows_neigh, int Fn, int64_t off_neigh,
+                      const gs_fused_segment *segs, int n_segs,
+                      const float *W_self, const float *W_neigh, const float *bias,
+                      int H, int act, int normalize,
+                      float *out, float *save_self, float *save_mean, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -401,3 +401,118 @@ def test_aggregator_layer_call_convention(cuda):
     close(out, want)
     with pytest.raises(NotImplementedError):
         ga.Aggregator(32, agg_option='max')
+
+
+# ------------------------------------------------- fused layer and engine ----
+
+@pytest.mark.parametrize('fs,fn,h', [(64, 64, 32), (32, 32, 32), (64, 64, 64), (128, 64, 32), (32, 128, 64)])
+@pytest.mark.parametrize('act,normalize', [('relu', False), ('linear', True)])
+def test_fused_layer_matches_oracle(cuda, fs, fn, h, act, normalize):
+    rng = np.random.default_rng(fs + fn + h)
+    gen = torch.Generator().manual_seed(fs * 7 + h)
+    n_self, n_neigh, off_s, off_n = 500, 300, 11, 1000
+    t_self = rng.standard_normal((n_self, fs)).astype(np.float32)
+    t_neigh = rng.standard_normal((n_neigh, fn)).astype(np.float32)
+    segs_np = []
+    for n_heads, n_child in [(37, 10), (1, 25), (130, 3)]:
+        heads = rng.integers(0, n_self, n_heads).astype(np.int32) + off_s
+        kids = rng.integers(0, n_neigh, n_heads * n_child).astype(np.int32) + off_n
+        segs_np.append((heads, kids, n_child))
+    segs_np[0][1][4] = -1                                     # sample below an isolated node
+    segs_np[2][0][7] = off_s + n_self                         # head outside the table
+    ws = omodel.glorot_uniform(fs, h // 2, gen, torch.float64)
+    wn = omodel.glorot_uniform(fn, h // 2, gen, torch.float64)
+    bias = torch.randn(h, generator=gen, dtype=torch.float64) * 0.1
+
+    def rows_of(table, ids, off):
+        ok = (ids - off >= 0) & (ids - off < len(table))
+        return np.where(ok[:, None], table[np.clip(ids - off, 0, len(table) - 1)], 0).astype(np.float64)
+
+    want, want_self, want_mean = [], [], []
+    for heads, kids, n_child in segs_np:
+        xs = torch.from_numpy(rows_of(t_self, heads, off_s))
+        xn = torch.from_numpy(rows_of(t_neigh, kids, off_n)).reshape(len(heads), 1, n_child, fn)
+        o = omodel.aggregator(xs[:, None, :], xn, ws, wn, bias, act)[:, 0, :]
+        want.append(omodel.l2_normalize(o) if normalize else o)
+        want_self.append(xs)
+        want_mean.append(xn.mean(2)[:, 0, :])
+    want = torch.cat(want)
+
+    d = lambda a: torch.from_numpy(a).to(cuda)
+    f32 = lambda t: t.float().to(cuda).contiguous()
+    segs = [{'head_ids': d(hh), 'child_ids': d(kk), 'n_heads': len(hh), 'n_child': nc} for hh, kk, nc in segs_np]
+    rows = sum(len(s[0]) for s in segs_np)
+    save_s = torch.empty((rows, fs), device=cuda)
+    save_m = torch.empty((rows, fn), device=cuda)
+    assert kernels.fused_supported(fs, fn, h, 25)
+    got = kernels.sage_fused(d(t_self), off_s, d(t_neigh), off_n, segs, f32(ws), f32(wn), f32(bias), act,
+                             normalize=normalize, save_self=save_s, save_mean=save_m)
+    close(got, want, scale=float(want.abs().max()))
+    np.testing.assert_array_equal(save_s.cpu().numpy(), torch.cat(want_self).float().numpy())
+    close(save_m, torch.cat(want_mean), scale=1.0)
+
+    # dense addressing (layer >= 1): heads and children are rows of activation buffers
+    n_heads, n_child = 45, 5
+    dense = [{'n_heads': n_heads, 'n_child': n_child, 'self_row0': 3, 'child_row0': 10}]
+    got2 = kernels.sage_fused(d(t_self), 0, d(t_neigh), 0, dense, f32(ws), f32(wn), None, act, normalize=normalize)
+    xs = torch.from_numpy(t_self[3:3 + n_heads].astype(np.float64))
+    xn = torch.from_numpy(t_neigh[10:10 + n_heads * n_child].astype(np.float64)).reshape(n_heads, 1, n_child, fn)
+    o = omodel.aggregator(xs[:, None, :], xn, ws, wn, None, act)[:, 0, :]
+    close(got2, omodel.l2_normalize(o) if normalize else o, scale=float(o.abs().max()))
+    with pytest.raises(Exception):                            # dense rows beyond the table
+        kernels.sage_fused(d(t_self), 0, d(t_neigh), 0, [{'n_heads': 100, 'n_child': 5, 'child_row0': 0}],
+                           f32(ws), f32(wn), None, act)
+    assert not kernels.fused_supported(24, 19, 32, 8) and not kernels.fused_supported(256, 256, 256, 5)
+
+
+@pytest.mark.parametrize('ns,sizes,fu,fi', [([8, 4], [32, 32], 64, 64), ([25, 10], [32, 32], 64, 32),
+                                            ([4, 3, 2], [32, 64, 32], 32, 64), ([8, 4], [32, 32], 24, 19)])
+def test_engine_fused_and_unfused_match_model_and_oracle(cuda, ns, sizes, fu, fi):
+    from graphsage_amd.engine import SageForwardEngine
+    rng = np.random.default_rng(3)
+    nu, ni, b = 200, 50, 24
+    u = np.concatenate([rng.integers(0, nu, 1500), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 1500), np.arange(nu) % ni]) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, fu)).astype(np.float32),
+             'item': rng.standard_normal((ni, fi)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=21)
+    model = ga.GraphSAGE(sizes, gen, seed=5).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.1, 0.1)
+    links = [(int(e[0, i]), int(e[1, i])) for i in range(b)]
+    seeds = torch.tensor([l[0] for l in links] + [l[1] for l in links], dtype=torch.int32, device=cuda)
+    walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda)
+
+    eng_f = SageForwardEngine(g, model, b, use_fused=True)
+    eng_u = SageForwardEngine(g, model, b, use_fused=False)
+    fused_shapes = fu % 32 == 0 and fi % 32 == 0
+    assert all(eng_f.fused_layers) == fused_shapes
+    out_f = [x.clone() for x in eng_f.forward(seeds, walk_ids, rng_seed=99)]
+    out_u = [x.clone() for x in eng_u.forward(seeds, walk_ids, rng_seed=99)]
+    assert eng_f.err_flag.tolist() == [0, 0]
+    for a, c in zip(eng_f.hops, eng_u.hops):
+        assert torch.equal(a, c)
+
+    # the oracle on the very same sampled ids
+    hops = [h.cpu().numpy().astype(np.int64) for h in eng_f.hops]
+    want_hops = walker.walk_vectorised(g.indptr, g.indices, seeds.cpu().numpy(), ns, rng_seed=99, first_walk=0)
+    for a, c in zip(hops, want_hops):
+        np.testing.assert_array_equal(a, c)
+    xin = ogen.sample_features_fast({k: v.astype(np.float64) for k, v in feats.items()}, nu, links, hops)
+    plan = omodel.LayerPlan(sizes, ns, g.node_feature_sizes)
+    want = omodel.forward(plan, _oracle_model(model, plan), [torch.from_numpy(x) for x in xin])
+    for k in range(2):
+        close(out_f[k], want[k], scale=1.0)
+        close(out_u[k], want[k], scale=1.0)
+    # second call on other seeds reuses the prepared launches
+    seeds2 = seeds.flip(0).contiguous()
+    seeds2 = torch.cat([seeds2[b:], seeds2[:b]])
+    o1 = [x.clone() for x in eng_f.forward(seeds2, walk_ids, rng_seed=5)]
+    o2 = [x.clone() for x in eng_u.forward(seeds2, walk_ids, rng_seed=5)]
+    for k in range(2):
+        close(o1[k], o2[k], scale=1.0)
+    assert not torch.equal(o1[0], out_f[0])
