@@ -1,29 +1,31 @@
 // Fused SAGE layer: feature gather + neighbor mean + both projections + bias +
-// activation (+ l2 normalisation) in one kernel, for the shapes whose weights
-// fit in registers (the reference model's: feature/hidden widths up to 128,
-// half-widths 16 or 32).
+// activation (+ l2 normalisation) in one kernel, for the shapes of the reference
+// model (feature/hidden widths 32..128, half-widths 16 or 32).
 //
 // Work unit: a wave owns a tile of 16 head nodes.
 //   1. ids   -- the tile's child ids (16 * n_child, contiguous) and head ids are
 //              staged into the wave's LDS region with coalesced loads.
-//   2. self  -- the 16 own rows are fetched row-contiguously (FS/4 lanes x 16 B
-//              per row) and written to the LDS tile A_self[16][FS+4].
+//   2. self  -- the loads of the 16 own rows are issued (row-contiguous, FS/4
+//              lanes x 16 B per row) and left in flight.
 //   3. mean  -- 64/(FN/4) lane groups each take every GN-th head of the tile and
-//              sum its n_child rows as they arrive (up to 8 row loads in flight
-//              per lane, 16 B per lane, whole rows per group), divide, and write
-//              the mean row to A_mean[16][FN+4].  The (heads, n_child, FN)
-//              neighbor tensor never exists in memory.
-//   4. mfma  -- D[16 x HH] = A[16 x F] . W[F x HH] on v_mfma_f32_16x16x4_f32 for
-//              both halves.  The order of k inside the dot product is free, so
-//              lane (row r = lane&15, quarter q = lane>>4) feeds the k-steps from
-//              its own contiguous quarter of the row, k = q*F/4 + step: A
-//              fragments are plain 16-byte LDS reads and the matching W
-//              fragments (W[q*F/4 + step][16*ct + r]) are loaded once per wave
-//              and stay in registers for all its tiles.
+//              sum its n_child rows as they arrive (all of a head's row loads in
+//              flight at once when n_child <= UNROLL, else balanced rounds; 16 B
+//              per lane, whole rows per group), divide, and write the mean row
+//              to the LDS tile A[16][F+4].  The (heads, n_child, FN) neighbor
+//              tensor never exists in memory.
+//   4. mfma  -- D[16 x HH] = A[16 x F] . W[F x HH] on v_mfma_f32_16x16x4_f32,
+//              first for the means, then the own rows go through the same LDS
+//              tile for the self half.  The order of k inside the dot product
+//              is free, so lane (row r = lane&15, quarter q = lane>>4) feeds the
+//              k-steps from its own contiguous quarter of the row, k = q*F/4 +
+//              step: A fragments are plain 16-byte LDS reads, and the matching W
+//              fragments W[q*F/4 + step][16*ct + r] sit in LDS in exactly the
+//              order the lanes read them (staged once per block).
 //   5. out   -- bias, relu/linear, optional row l2-normalisation (sum of squares
 //              over the 16 lanes that share a row via xor-shuffles), 64-byte
 //              contiguous stores per row and half.
-// Waves never synchronise with each other: all LDS hand-offs are wave-local.
+// After the one-time weight staging, waves never synchronise with each other:
+// all LDS hand-offs are wave-local.
 #include "gs_common.h"
 
 namespace {
@@ -32,7 +34,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kWaves = 4;
 constexpr int kMaxSegs = 2 * GS_MAX_HOPS;
-constexpr int kUnroll = 8;
+constexpr int kUnroll = 10;
+constexpr size_t kLdsLimit = 64 * 1024;
 
 struct Seg {
     const int32_t *head_ids;   // node ids of the heads, or NULL: heads are rows self_row0 + p of feat_self
@@ -63,42 +66,55 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 template <int FS, int FN, int HH>
-__global__ __launch_bounds__(kWaves * 64)
+struct FusedShape {
+    static constexpr int FMAX = FS > FN ? FS : FN;
+    static constexpr int LDA = FMAX + 4;
+    static constexpr int NT = HH / 16;
+    static constexpr int KS_S = FS / 4, KS_N = FN / 4;
+    static constexpr int W_FLOATS = (KS_S + KS_N) * NT * 64;
+    static size_t lds_bytes(int max_child) {
+        return (size_t)(W_FLOATS + kWaves * (16 * LDA + 16 * max_child + 16)) * sizeof(float);
+    }
+};
+
+template <int FS, int FN, int HH, bool DENSE>
+__global__ __launch_bounds__(kWaves * 64, 4)
 void sage_fused_kernel(const FusedArgs a) {
     static_assert(FS % 16 == 0 && FN % 16 == 0 && HH % 16 == 0, "widths must be multiples of 16");
-    constexpr int LDA_S = FS + 4, LDA_N = FN + 4;
-    constexpr int NT = HH / 16;
-    constexpr int KS_S = FS / 4, KS_N = FN / 4;          // k-steps per operand
+    using S = FusedShape<FS, FN, HH>;
+    constexpr int LDA = S::LDA, NT = S::NT, KS_S = S::KS_S, KS_N = S::KS_N;
     constexpr int FSV = FS / 4, FNV = FN / 4;            // lanes per row (float4 each)
-    constexpr int RP_S = 64 / FSV;                       // self rows per load instruction
+    constexpr int RP_S = 64 / FSV;                       // own rows per load instruction
+    constexpr int NPASS = 16 / RP_S;
     constexpr int GN = 64 / FNV;                         // lane groups in the mean phase
     constexpr int H = 2 * HH;
 
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int per_wave = 16 * LDA_S + 16 * LDA_N + 16 * a.max_child + 16;
-    float *As = lds + (size_t)wave * per_wave;
-    float *An = As + 16 * LDA_S;
-    int32_t *s_child = reinterpret_cast<int32_t *>(An + 16 * LDA_N);
+    float *Wl_s = lds;                                   // [KS_S][NT][64] fragment order
+    float *Wl_n = Wl_s + KS_S * NT * 64;
+    const int per_wave = 16 * LDA + 16 * a.max_child + 16;
+    float *A = Wl_n + KS_N * NT * 64 + (size_t)wave * per_wave;
+    int32_t *s_child = reinterpret_cast<int32_t *>(A + 16 * LDA);
     int32_t *s_head = s_child + 16 * a.max_child;
 
     const int r = lane & 15, q = lane >> 4;
 
-    // weight fragments, resident for the whole kernel
-    float bs[KS_S][NT], bn[KS_N][NT];
-#pragma unroll
-    for (int ks = 0; ks < KS_S; ++ks)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) bs[ks][ct] = a.W_self[(size_t)(q * KS_S + ks) * HH + ct * 16 + r];
-#pragma unroll
-    for (int ks = 0; ks < KS_N; ++ks)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) bn[ks][ct] = a.W_neigh[(size_t)(q * KS_N + ks) * HH + ct * 16 + r];
+    // weight fragments in the order lanes consume them: [(ks*NT + ct)*64 + 16 q + r]
+    for (int idx = threadIdx.x; idx < KS_S * NT * 64; idx += kWaves * 64) {
+        const int rr = idx & 15, qq = (idx >> 4) & 3, ct = (idx >> 6) % NT, ks = (idx >> 6) / NT;
+        Wl_s[idx] = a.W_self[(size_t)(qq * KS_S + ks) * HH + ct * 16 + rr];
+    }
+    for (int idx = threadIdx.x; idx < KS_N * NT * 64; idx += kWaves * 64) {
+        const int rr = idx & 15, qq = (idx >> 4) & 3, ct = (idx >> 6) % NT, ks = (idx >> 6) / NT;
+        Wl_n[idx] = a.W_neigh[(size_t)(qq * KS_N + ks) * HH + ct * 16 + rr];
+    }
     float bias_v[2][NT];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) bias_v[hf][ct] = a.bias ? a.bias[hf * HH + ct * 16 + r] : 0.f;
+    __syncthreads();
 
     for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < a.n_tiles;
          tile += (long long)gridDim.x * kWaves) {
@@ -117,7 +133,7 @@ void sage_fused_kernel(const FusedArgs a) {
 
         // 1. ids
         wave_lds_fence();                                   // previous tile's LDS reads are done
-        if (child_ids) {
+        if (!DENSE) {
             const int32_t *src = child_ids + p0 * n;
             for (int i = lane; i < np * n; i += 64) s_child[i] = src[i];
         }
@@ -129,75 +145,96 @@ void sage_fused_kernel(const FusedArgs a) {
         }
         wave_lds_fence();
 
-        // 2. own rows
+        // 2. own rows: issue the loads, consume them after the mean phase.  Invalid rows read
+        // row 0 and are zeroed by a select, so the load stream has no branches.
+        float4 own[NPASS];
 #pragma unroll
-        for (int pass = 0; pass < 16 / RP_S; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int rr = pass * RP_S + lane / FSV, c = lane % FSV;
             const int32_t row = s_head[rr];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row >= 0) v = reinterpret_cast<const float4 *>(a.feat_self + (size_t)row * FS)[c];
-            *reinterpret_cast<float4 *>(As + rr * LDA_S + 4 * c) = v;
-            if (a.save_self && rr < np)
-                reinterpret_cast<float4 *>(a.save_self + (size_t)(out_row0 + p0 + rr) * FS)[c] = v;
+            const float4 t = reinterpret_cast<const float4 *>(a.feat_self + (size_t)(row >= 0 ? row : 0) * FS)[c];
+            own[pass] = row >= 0 ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 
-        // 3. neighbor means
+        // 3. neighbor means -> A
         {
             const int g = lane / FNV, c = lane % FNV;
             const float denom = (float)n;
+            const int rounds = (n + kUnroll - 1) / kUnroll;
+            const int per = (n + rounds - 1) / rounds;
+            const float4 *table = reinterpret_cast<const float4 *>(a.feat_neigh) + c;
             for (int pp = g; pp < 16; pp += GN) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (pp < np) {
-                    for (int j0 = 0; j0 < n; j0 += kUnroll) {
+                    const int32_t *ids = s_child + pp * n;
+                    const long long dense0 = child_row0 + (p0 + pp) * n;
+                    for (int j0 = 0; j0 < n; j0 += per) {
                         float4 v[kUnroll];
+                        unsigned okmask = 0;
 #pragma unroll
                         for (int u = 0; u < kUnroll; ++u) {
-                            const int j = j0 + u;
-                            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (j < n) {
-                                const long long row = child_ids ? (long long)s_child[pp * n + j] - a.off_neigh
-                                                                : child_row0 + (p0 + pp) * n + j;
-                                if ((unsigned long long)row < (unsigned long long)a.n_rows_neigh)
-                                    v[u] = reinterpret_cast<const float4 *>(a.feat_neigh + (size_t)row * FN)[c];
-                            }
+                            const int j = min(j0 + u, n - 1);
+                            const long long rw = DENSE ? dense0 + j : (long long)ids[j] - a.off_neigh;
+                            const bool ok = (u < per) && (j0 + u < n) &&
+                                            ((unsigned long long)rw < (unsigned long long)a.n_rows_neigh);
+                            okmask |= (unsigned)ok << u;
+                            v[u] = table[(ok ? rw : 0) * FNV];
                         }
 #pragma unroll
                         for (int u = 0; u < kUnroll; ++u) {
-                            acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                            const bool ok = (okmask >> u) & 1;
+                            acc.x += ok ? v[u].x : 0.f; acc.y += ok ? v[u].y : 0.f;
+                            acc.z += ok ? v[u].z : 0.f; acc.w += ok ? v[u].w : 0.f;
                         }
                     }
                     acc.x /= denom; acc.y /= denom; acc.z /= denom; acc.w /= denom;
                     if (a.save_mean)
                         reinterpret_cast<float4 *>(a.save_mean + (size_t)(out_row0 + p0 + pp) * FN)[c] = acc;
                 }
-                *reinterpret_cast<float4 *>(An + pp * LDA_N + 4 * c) = acc;
+                *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) = acc;
             }
         }
         wave_lds_fence();
 
-        // 4. projections
+        // 4a. neighbor half.  The fragment offset goes through an empty asm so the weight
+        // reads stay inside the tile loop instead of being hoisted into 2*F/4 registers.
+        int wl = lane;
+        asm volatile("" : "+v"(wl));
         f32x4 acc_s[NT], acc_n[NT];
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int k4 = 0; k4 < KS_S / 4; ++k4) {
-            const float4 av = *reinterpret_cast<const float4 *>(As + r * LDA_S + q * KS_S + 4 * k4);
-            const float ae[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct)
-                    acc_s[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], bs[4 * k4 + e][ct], acc_s[ct], 0, 0, 0);
-        }
-#pragma unroll
         for (int k4 = 0; k4 < KS_N / 4; ++k4) {
-            const float4 av = *reinterpret_cast<const float4 *>(An + r * LDA_N + q * KS_N + 4 * k4);
+            const float4 av = *reinterpret_cast<const float4 *>(A + r * LDA + q * KS_N + 4 * k4);
             const float ae[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int ct = 0; ct < NT; ++ct)
-                    acc_n[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], bn[4 * k4 + e][ct], acc_n[ct], 0, 0, 0);
+                    acc_n[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], Wl_n[((4 * k4 + e) * NT + ct) * 64 + wl],
+                                                                     acc_n[ct], 0, 0, 0);
+        }
+        wave_lds_fence();                                   // A is free again
+
+        // 4b. own rows -> A -> self half
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int rr = pass * RP_S + lane / FSV, c = lane % FSV;
+            *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = own[pass];
+            if (a.save_self && rr < np)
+                reinterpret_cast<float4 *>(a.save_self + (size_t)(out_row0 + p0 + rr) * FS)[c] = own[pass];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int k4 = 0; k4 < KS_S / 4; ++k4) {
+            const float4 av = *reinterpret_cast<const float4 *>(A + r * LDA + q * KS_S + 4 * k4);
+            const float ae[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+                    acc_s[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], Wl_s[((4 * k4 + e) * NT + ct) * 64 + wl],
+                                                                     acc_s[ct], 0, 0, 0);
         }
 
         // 5. epilogue: D[row = 4q + i][col = 16 ct + r]
@@ -241,14 +278,21 @@ void sage_fused_kernel(const FusedArgs a) {
 
 template <int FS, int FN, int HH>
 int launch(const FusedArgs &a, hipStream_t stream) {
-    const size_t per_wave = (size_t)(16 * (FS + 4) + 16 * (FN + 4) + 16 * a.max_child + 16) * sizeof(float);
-    const size_t lds = per_wave * kWaves;
-    if (lds > 64 * 1024) return gs::fail(GS_ELIMIT, "gs_sage_fused_fwd: %zu B of LDS per block needed (limit 65536)", lds);
+    const size_t lds = FusedShape<FS, FN, HH>::lds_bytes(a.max_child);
+    if (lds > kLdsLimit) return gs::fail(GS_ELIMIT, "gs_sage_fused_fwd: %zu B of LDS per block needed (limit %zu)", lds, kLdsLimit);
     long long blocks = (a.n_tiles + kWaves - 1) / kWaves;
     const long long cap = 256 * 8;                      // a few blocks per CU; waves loop over tiles
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((sage_fused_kernel<FS, FN, HH>), dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
+    if (a.seg[0].child_ids)
+        hipLaunchKernelGGL((sage_fused_kernel<FS, FN, HH, false>), dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
+    else
+        hipLaunchKernelGGL((sage_fused_kernel<FS, FN, HH, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
     return gs::check_launch("gs_sage_fused_fwd");
+}
+
+inline size_t fused_lds_bytes(int Fs, int Fn, int hh, int max_child) {
+    const int fmax = Fs > Fn ? Fs : Fn;
+    return (size_t)((Fs / 4 + Fn / 4) * (hh / 16) * 64 + kWaves * (16 * (fmax + 4) + 16 * max_child + 16)) * sizeof(float);
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -260,9 +304,7 @@ extern "C" int gs_sage_fused_supported(int Fs, int Fn, int H, int max_child) {
     const bool f_ok = (Fs == 32 || Fs == 64 || Fs == 128) && (Fn == 32 || Fn == 64 || Fn == 128);
     const bool h_ok = (H % 2 == 0) && (hh == 16 || hh == 32);
     if (!f_ok || !h_ok || max_child < 1) return 0;
-    if ((Fs + Fn) / 4 * (hh / 16) > 96) return 0;       // weight fragments must stay in registers
-    const size_t lds = (size_t)(16 * (Fs + 4) + 16 * (Fn + 4) + 16 * max_child + 16) * 4 * kWaves;
-    return lds <= 64 * 1024;
+    return fused_lds_bytes(Fs, Fn, hh, max_child) <= kLdsLimit;
 }
 
 extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
@@ -284,6 +326,8 @@ extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, in
             return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: segment %d dense head rows exceed feat_self", s);
         if (!g.child_ids && (g.child_row0 < 0 || g.child_row0 + g.n_heads * g.n_child > n_rows_neigh))
             return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: segment %d dense child rows exceed feat_neigh", s);
+        if (s > 0 && (g.child_ids == nullptr) != (segs[0].child_ids == nullptr))
+            return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: segments must all give child ids or all be dense");
         Seg &d = a.seg[s];
         d.head_ids = g.head_ids; d.child_ids = g.child_ids; d.n_heads = g.n_heads;
         d.self_row0 = g.self_row0; d.child_row0 = g.child_row0; d.n_child = g.n_child;
@@ -295,6 +339,8 @@ extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, in
     if (tiles == 0) return GS_OK;
     if (!feat_self || !feat_neigh || !W_self || !W_neigh || !out)
         return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: null pointer argument");
+    if (n_rows_self < 1 || n_rows_neigh < 1)
+        return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: feature tables must have at least one row");
     if (!aligned16(feat_self) || !aligned16(feat_neigh) || (save_self && !aligned16(save_self)) || (save_mean && !aligned16(save_mean)))
         return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: feature tables and save buffers must be 16-byte aligned");
     if (!gs_sage_fused_supported(Fs, Fn, H, max_child))
@@ -311,7 +357,7 @@ extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, in
     GS_CASE(64, 64, 16) GS_CASE(64, 64, 32)
     GS_CASE(32, 32, 16) GS_CASE(32, 32, 32)
     GS_CASE(64, 32, 16) GS_CASE(32, 64, 16) GS_CASE(64, 32, 32) GS_CASE(32, 64, 32)
-    GS_CASE(128, 128, 16)
+    GS_CASE(128, 128, 16) GS_CASE(128, 128, 32)
     GS_CASE(128, 64, 16) GS_CASE(64, 128, 16) GS_CASE(128, 32, 16) GS_CASE(32, 128, 16)
     GS_CASE(128, 64, 32) GS_CASE(64, 128, 32) GS_CASE(128, 32, 32) GS_CASE(32, 128, 32)
 #undef GS_CASE

@@ -67,10 +67,7 @@ class SageForwardEngine:
         self.err_flag = torch.zeros(2, dtype=torch.int32, device=device)
         self._hop_ptrs = None
         self.probes = None           # list to receive (start, end) events around the dominant launches
-        # static inputs: a step copies its roots / walk ids here, so every launch of the plan
-        # sees fixed addresses (prepared argument lists, HIP-graph capture)
-        self.seeds_buf = torch.zeros(2 * b, dtype=torch.int32, device=device)
-        self.walk_buf = torch.zeros(2 * b, dtype=torch.int64, device=device)
+        self.seeds_buf = torch.zeros(2 * b, dtype=torch.int32, device=device)   # placeholder roots
         self.use_fused = use_fused
         self.fused_layers = [self._fused_ok(layer) and use_fused for layer in range(self.n_hops)]
         self._fused_calls = {}
@@ -184,9 +181,14 @@ class SageForwardEngine:
         self._fused_calls[key] = call
         return call
 
-    def _run_fused_layer(self, layer):
+    def _run_fused_layer(self, layer, seeds):
         for t in _TYPES:
             call = self._fused_call(layer, t)
+            if layer == 0:
+                # the roots are the only ids that change address from step to step
+                for i, (_, h, side, _, _) in enumerate(self.segments[t]):
+                    if h == 0:
+                        call.set_head_ids(i, self._slot_ids(seeds, 0, side))
             if self.probes is not None and layer == 0:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -196,25 +198,19 @@ class SageForwardEngine:
             else:
                 call.run()
 
-    def aggregate_fused(self):
-        """Same result as ``aggregate`` with one kernel per (layer, node type) for
-        the layers the fused kernel covers; ids come from ``seeds_buf``/``hops``."""
+    def aggregate_fused(self, seeds):
+        """Same result as ``aggregate`` with one kernel per (layer, node type)."""
         if not all(self.fused_layers):
-            return self.aggregate(self.seeds_buf)
+            return self.aggregate(seeds)
         for layer in range(self.n_hops):
-            self._run_fused_layer(layer)
-        if self.model.normalize != "l2":
-            pass                                     # emb already holds the last layer's output
+            self._run_fused_layer(layer, seeds)
         return self.emb['user'], self.emb['item']
 
     def forward(self, seeds, walk_ids=None, rng_seed=0, replay=None):
-        self.seeds_buf.copy_(seeds)
-        if walk_ids is not None:
-            self.walk_buf.copy_(walk_ids)
-        self.sample(self.seeds_buf, self.walk_buf if walk_ids is not None else None, rng_seed, replay)
+        self.sample(seeds, walk_ids, rng_seed, replay)
         if self.use_fused and all(self.fused_layers):
-            return self.aggregate_fused()
-        return self.aggregate(self.seeds_buf)
+            return self.aggregate_fused(seeds)
+        return self.aggregate(seeds)
 
     # -- accounting for the benchmark --------------------------------------------
     def dominant_name(self):

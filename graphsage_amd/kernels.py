@@ -263,11 +263,21 @@ class FusedLayerCall:
             raise _lib.GsageError("fused layer kernel does not cover Fs=%d Fn=%d H=%d n_child=%d" %
                                   (fs, fn, 2 * hh, max_child))
         self._lib = lib
+        self._arr = arr
+        self._live_heads = {}
         self._keep += [feat_self, feat_neigh, w_self, w_neigh, bias, out, save_self, save_mean]
         self._args = (ptr(feat_self), feat_self.shape[0], fs, int(off_self), ptr(feat_neigh), feat_neigh.shape[0],
                       fn, int(off_neigh), arr, len(segments), ptr(w_self), ptr(w_neigh), ptr(bias), 2 * hh,
                       ACT[act], int(bool(normalize)), ptr(out), ptr(save_self), ptr(save_mean))
         self.out = out
+
+    def set_head_ids(self, seg, head_ids):
+        """Points segment ``seg`` at another head-id array of the same length."""
+        _dev(head_ids, torch.int32, 'head_ids')
+        if head_ids.numel() != self._arr[seg].n_heads:
+            raise ValueError("head_ids has %d entries, %d needed" % (head_ids.numel(), self._arr[seg].n_heads))
+        self._arr[seg].head_ids = head_ids.data_ptr()
+        self._live_heads[seg] = head_ids
 
     def run(self):
         check(self._lib.gs_sage_fused_fwd(*self._args, stream_handle()), 'gs_sage_fused_fwd')

@@ -1,0 +1,96 @@
+"""Training step on the GPU against the float64 oracle: loss, every gradient,
+and the parameters after one Adam update; then a short run must learn."""
+import numpy as np
+import pytest
+import torch
+
+import graphsage_amd as ga
+from graphsage_amd.train import Trainer
+from oracle import model as omodel
+
+pytestmark = pytest.mark.gpu
+
+
+def _toy(seed=0, nu=150, ni=40, fu=24, fi=19):
+    rng = np.random.default_rng(seed)
+    # two user communities and two item communities; positive links inside a community
+    cu, ci = rng.integers(0, 2, nu), rng.integers(0, 2, ni)
+    u = rng.integers(0, nu, 4000)
+    it = rng.integers(0, ni, 4000)
+    keep = cu[u] == ci[it]
+    u, it = np.concatenate([u[keep], np.arange(nu)]), np.concatenate([it[keep], np.arange(nu) % ni])
+    e = np.stack([u, it + nu])
+    feats = {'user': (rng.standard_normal((nu, fu)) + cu[:, None]).astype(np.float32),
+             'item': (rng.standard_normal((ni, fi)) - ci[:, None]).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    lu, li = rng.integers(0, nu, 600), rng.integers(0, ni, 600)
+    links = [(int(a), int(b) + nu) for a, b in zip(lu, li)]
+    targets = (cu[lu] == ci[li]).astype(np.float32)
+    return g, links, targets
+
+
+def test_one_step_matches_oracle(cuda):
+    g, links, targets = _toy()
+    b, ns, sizes = 64, [8, 4], [32, 32]
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+    model = ga.GraphSAGE(sizes, gen, seed=11)
+    tr = Trainer(model, lr=1e-2)
+    seq = gen.flow(links, targets=targets, shuffle=False)
+    batch, t = seq[0]
+    before = [p.detach().cpu().double().clone() for p in tr.params]
+
+    # oracle: same batch tensors, same weights, float64
+    plan = omodel.LayerPlan(sizes, ns, g.node_feature_sizes)
+    weights = {(l, ty): {'w_self': a.w_self.detach().cpu().double().requires_grad_(True),
+                         'w_neigh': a.w_neigh.detach().cpu().double().requires_grad_(True),
+                         'bias': a.bias.detach().cpu().double().requires_grad_(True)}
+               for l, aggs in enumerate(model._aggs) for ty, a in aggs.items()}
+    kernel = tr.head.kernel.detach().cpu().double().requires_grad_(True)
+    hbias = tr.head.bias.detach().cpu().double().requires_grad_(True)
+    emb = omodel.forward(plan, weights, [torch.from_numpy(x).double() for x in batch.numpy()])
+    want_loss = omodel.mse_loss(omodel.link_head(emb[0], emb[1], kernel, hbias), torch.from_numpy(t).double())
+    want_loss.backward()
+
+    loss, pred = tr.step(batch, t)
+    assert abs(float(loss) - float(want_loss)) < 1e-5 * max(1.0, float(want_loss))
+    ref_params = [weights[(l, ty)][n] for l, aggs in enumerate(model._aggs) for ty, a in aggs.items()
+                  for n in ('w_self', 'w_neigh', 'bias')] + [kernel, hbias]
+    assert len(ref_params) == len(tr.params)
+    off = 0
+    for p, ref, old in zip(tr.params, ref_params, before):
+        grad = tr.bucket.flat[off:off + p.numel()].view_as(p).cpu().double()
+        off += p.numel()
+        scale = float(ref.grad.abs().max()) + 1e-12
+        assert float((grad - ref.grad).abs().max()) <= 2e-5 * scale
+        # first Adam step: p - lr * g / (|g| + eps')  with bias correction
+        m, v = 0.1 * ref.grad, 0.001 * ref.grad ** 2
+        want = old - 1e-2 * (1 - 0.999) ** 0.5 / (1 - 0.9) * m / (v.sqrt() + 1e-7)
+        got = p.detach().cpu().double()
+        big = ref.grad.abs() > 1e-4 * scale                    # sign of tiny gradients is rounding noise
+        assert float((got - want)[big].abs().max()) < 1e-4 if big.any() else True
+
+
+def test_short_run_learns(cuda):
+    g, links, targets = _toy(1)
+    gen = ga.GraphSAGEGenerator(g, 100, [8, 4], head_node_types=['user', 'item'], seed=5)
+    model = ga.GraphSAGE([32, 32], gen, seed=2)
+    tr = Trainer(model, lr=1e-2)
+    seq = gen.flow(links, targets=targets, shuffle=True, seed=1)
+    losses = []
+    for epoch in range(6):
+        tot = 0.0
+        for batch, t in seq:
+            loss, _ = tr.step(batch, t)
+            tot += float(loss)
+        losses.append(tot / len(seq))
+        seq.on_epoch_end()
+    assert losses[-1] < 0.6 * losses[0], losses
+    preds, ys = [], []
+    model.eval()
+    with torch.no_grad():
+        for batch, t in gen.flow(links, targets=targets, shuffle=False):
+            preds.append(tr.head(model(batch)).cpu().numpy())
+            ys.append(t)
+    auc = omodel.keras_auc(np.concatenate(ys), np.concatenate(preds))
+    assert auc > 0.85, auc
