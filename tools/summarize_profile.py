@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condenses a gpurun_out/prof_<tag> directory (tools/profile_gpu.sh) into
+profiles/<name>.md: per-kernel time from the kernel trace, and HBM traffic per
+launch of our kernels from the FETCH_SIZE / WRITE_SIZE passes.
+
+gfx950 counter corrections: FETCH_SIZE and WRITE_SIZE are reported in KiB;
+FETCH_SIZE counts 128-byte read requests as 64 bytes for wide coalesced reads, so
+the read side is doubled (upper estimate; narrower accesses are uncalibrated)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+src, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ours = ('sage_fused_kernel', 'sample_kernel', 'gather_mean_kernel', 'gather_rows_kernel', 'rows_gemm_kernel',
+        'wgrad_kernel', 'wgrad_reduce_kernel', 'l2norm')
+
+
+def short(n):
+    for o in ours:
+        if o in n:
+            tail = n[n.index(o):]
+            return tail.split('(')[0][:60]
+    return n[:60]
+
+
+lines = ['# rocprofv3 summary: %s' % name, '']
+bl = os.path.join(src, 'bench_line.json')
+if os.path.exists(bl):
+    lines += ['bench line of the traced run:', '', '```', open(bl).read().strip(), '```', '']
+stats = glob.glob(os.path.join(src, 'trace', '*', '*kernel_stats.csv'))
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    lines += ['## kernel time (rocprofv3 --kernel-trace --stats), kernels of libgsage.so', '',
+              '| kernel | calls | total ms | avg us | min us | max us |', '|---|---|---|---|---|---|']
+    for r in rows:
+        if any(o in r['Name'] for o in ours):
+            lines.append('| %s | %s | %.3f | %.2f | %.2f | %.2f |' % (
+                short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3,
+                float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3))
+    lines.append('')
+
+traffic = {}
+for kind, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+    files = glob.glob(os.path.join(src, kind, '*', '*counter_collection.csv'))
+    if not files:
+        continue
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r.get('Counter_Name') == counter and any(o in r['Kernel_Name'] for o in ours):
+            acc[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
+    for k, v in acc.items():
+        traffic.setdefault(k, {})[kind] = (sum(v) / len(v) * 1024.0, len(v))
+if traffic:
+    lines += ['## HBM-side traffic per launch (rocprofv3 --pmc, separate passes)', '',
+              '| kernel | launches | FETCH_SIZE raw MB | read MB (x2 gfx950 correction) | WRITE_SIZE MB |',
+              '|---|---|---|---|---|']
+    for k, d in sorted(traffic.items()):
+        f, nf = d.get('fetch', (0.0, 0))
+        w, _ = d.get('write', (0.0, 0))
+        lines.append('| %s | %d | %.2f | %.2f | %.2f |' % (k, nf, f / 1e6, 2 * f / 1e6, w / 1e6))
+    lines.append('')
+os.makedirs(os.path.join(root, 'profiles'), exist_ok=True)
+with open(os.path.join(root, 'profiles', name + '.md'), 'w') as fh:
+    fh.write('\n'.join(lines) + '\n')
+if stats:
+    import shutil
+    shutil.copy(stats[0], os.path.join(root, 'profiles', name + '_kernel_stats.csv'))
+print('\n'.join(lines))
+json.dump({k: {kk: vv[0] for kk, vv in d.items()} for k, d in traffic.items()},
+          open(os.path.join(root, 'profiles', name + '_traffic_raw.json'), 'w'), indent=1)
