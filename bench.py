@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--seed-pool', type=int, default=1 << 20, help='seed edges drawn from the first N edges')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batches', type=int, default=10)
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL)')
     return ap.parse_args()
 
 
@@ -99,10 +100,15 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(args.backend)
+    sync_dev = device if args.backend == 'nccl' else torch.device('cpu')
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 
@@ -151,7 +157,7 @@ def main():
     elapsed = time.perf_counter() - t0
     engine.probes = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=sync_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     err = engine.err_flag.tolist()

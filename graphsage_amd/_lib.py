@@ -48,6 +48,20 @@ SIGNATURES['gs_sage_fused_fwd'] = (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _i32
                                           _c.POINTER(FusedSegment), _i32, _vp, _vp, _vp, _i32, _i32, _i32,
                                           _vp, _vp, _vp, _vp])
 
+
+
+class SageWeights(_c.Structure):
+    """gs_sage_weights of include/gsage.h."""
+    _fields_ = [('w_self', _vp), ('w_neigh', _vp), ('bias', _vp)]
+
+
+SIGNATURES['gs_sage2_supported'] = (_i32, [_i32] * 6)
+SIGNATURES['gs_sage2_forward'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
+                                         _u64, _u64, _vp, _vp,
+                                         _c.POINTER(SageWeights), _c.POINTER(SageWeights),
+                                         _c.POINTER(SageWeights), _c.POINTER(SageWeights),
+                                         _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp])
+
 _lib = None
 
 

@@ -1,0 +1,498 @@
+// Two-hop forward pass in ONE kernel: sampling, both aggregator layers and the
+// l2 normalisation, one wavefront per walk (= one root of a seed edge).
+//
+// The reference's generator and model are written for exactly two hops
+// (generator.py:239-244,339-345); for that case every quantity a root's
+// embedding depends on is private to its walk:
+//
+//   root r (type T) -- n0 sampled neighbors h_j (type O) -- n1 sampled
+//   neighbors c_jk (type T) each
+//   layer 0:  z_j = relu(W0_O . [x_O(h_j) ; mean_k x_T(c_jk)] + b0_O)      j < n0
+//             z_r = relu(W0_T . [x_T(r)   ; mean_j x_O(h_j)]  + b0_T)
+//   layer 1:  e_r = l2norm(W1_T . [z_r ; mean_j z_j] + b1_T)
+//
+// so a wave can sample its walk into LDS, stream the 1 + n0 + n0*n1 feature rows
+// exactly once (the rows of the h_j feed both z_j and the root's neighbor mean),
+// keep the layer-0 activations in LDS and write nothing but the final embedding
+// row.  Neither the sampled ids nor any intermediate tensor touch memory unless
+// the caller asks for the ids.
+//
+// Per wave: hop-1 heads are processed in tiles of 16 (own rows issued first and
+// left in flight, the children's rows summed as they arrive by 64/(F/4) lane
+// groups, both halves of the projection on v_mfma_f32_16x16x4_f32 through one
+// LDS A-tile), then the root's tile, then layer 1 on the LDS-resident
+// activations.  All weight matrices of the model sit in LDS in MFMA B-fragment
+// order (staged once per block); a lane's k-steps walk its own contiguous
+// quarter of the A row (k = q*K/4 + step), which is legal because the order of
+// the terms of a dot product is free.  Waves never synchronise with each other
+// after the weight staging: every LDS hand-off is wave-local.
+#include "gs_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kWaves = 12;               // most waves per block: one block per CU, 3 waves per SIMD
+constexpr int kUnroll = 10;              // row loads in flight per lane in the mean phase
+constexpr int kChunks = 4;               // 64-slot chunks sampled per pass
+constexpr size_t kLdsMax = 160 * 1024;
+
+struct Sage2Args {
+    const int64_t *indptr; const int32_t *indices; long long n_nodes;
+    const float *feat[2]; long long n_rows[2];         // [0] users, [1] items; item id offset = n_rows[0]
+    const int32_t *seeds; long long n_pairs;
+    int n0, n1;
+    unsigned key0, key1; unsigned long long walk_base;
+    const int64_t *walk_ids; const uint32_t *replay;
+    const float *w0_self[2], *w0_neigh[2], *b0[2];     // layer 0, by head type
+    const float *w1_self[2], *w1_neigh[2], *b1[2];     // layer 1, by head type
+    int normalize;
+    float *emb; int32_t *out_hop1, *out_hop2; int32_t *err;
+    int ids_per_wave, h1_rows;
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// D[16 x 16*NT] += A[16 x K] . W[K x 16*NT]; A in LDS (row stride lda), W in fragment order.
+template <int K, int NT>
+__device__ __forceinline__ void mma_tile(const float *A, int lda, const float *Wl, int wl, int r, int q,
+                                         f32x4 (&acc)[NT]) {
+#pragma unroll
+    for (int k4 = 0; k4 < K / 16; ++k4) {
+        const float4 av = *reinterpret_cast<const float4 *>(A + r * lda + q * (K / 4) + 4 * k4);
+        const float ae[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], Wl[((4 * k4 + e) * NT + ct) * 64 + wl], acc[ct], 0, 0, 0);
+    }
+}
+
+// stages W[K x HH] (row-major, global) into LDS fragment order [(ks*NT + ct)*64 + 16 q + r]
+__device__ __forceinline__ void stage_weight(float *dst, const float *W, int K, int HH) {
+    const int NT = HH / 16, KS = K / 4;
+    for (int idx = threadIdx.x; idx < KS * NT * 64; idx += blockDim.x) {
+        const int rr = idx & 15, qq = (idx >> 4) & 3, ct = (idx >> 6) % NT, ks = (idx >> 6) / NT;
+        dst[idx] = W[(size_t)(qq * KS + ks) * HH + ct * 16 + rr];
+    }
+}
+
+template <int FU, int FI, int HH1, int HH2>
+struct Sage2Shape {
+    static constexpr int FMAX = FU > FI ? FU : FI;
+    static constexpr int H1 = 2 * HH1, H2 = 2 * HH2;
+    static constexpr int KMAX = FMAX > H1 ? FMAX : H1;
+    static constexpr int LDA = KMAX + 4;
+    static constexpr int LDH = H1 + 4;
+    static constexpr int NT1 = HH1 / 16, NT2 = HH2 / 16;
+    // fragment floats: layer 0 per type (self: own width, neigh: other width), layer 1 per type (2 x H1)
+    static constexpr int W0_FLOATS = 2 * (FU + FI) * HH1;
+    static constexpr int W1_FLOATS = 4 * H1 * HH2;
+    static constexpr int B_FLOATS = 2 * H1 + 2 * H2;
+    static size_t lds_bytes(int n0, int n1, int waves) {
+        const int ids = ((n0 + n0 * n1) + 3) & ~3;
+        const int h1_rows = 1 + n0;
+        return (size_t)(W0_FLOATS + W1_FLOATS + B_FLOATS + waves * (16 * LDA + h1_rows * LDH + ids)) * sizeof(float);
+    }
+};
+
+// One walk.  FT / FO: feature widths of the root's type and of the other type.
+template <int FT, int FO, int HH1, int HH2, int LDA, int LDH>
+__device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int side, int lane,
+                                          float *A, float *H1t, int32_t *s_ids,
+                                          const float *W0s_T, const float *W0n_T, const float *W0s_O, const float *W0n_O,
+                                          const float *W1s_T, const float *W1n_T,
+                                          const float *b0_T, const float *b0_O, const float *b1_T) {
+    constexpr int NT1 = HH1 / 16, NT2 = HH2 / 16, H1 = 2 * HH1, H2 = 2 * HH2;
+    constexpr int FTV = FT / 4, FOV = FO / 4, H1V = H1 / 4;
+    const int r = lane & 15, q = lane >> 4;
+    const int n0 = a.n0, n1 = a.n1;
+    const float *tableT = a.feat[side], *tableO = a.feat[1 - side];
+    const long long rowsT = a.n_rows[side], rowsO = a.n_rows[1 - side];
+    const long long offT = side ? a.n_rows[0] : 0, offO = side ? 0 : a.n_rows[0];
+    int32_t *hop1 = s_ids, *hop2 = s_ids + n0;
+    int wl = lane;
+    asm volatile("" : "+v"(wl));            // keeps the weight-fragment reads inside the walk loop
+
+    // ---- sampling ---------------------------------------------------------------
+    int32_t root = a.seeds[w];
+    if ((unsigned long long)(long long)root >= (unsigned long long)a.n_nodes) {
+        if (lane == 0) atomicMax(&a.err[1], 1);
+        root = -1;
+    }
+    const unsigned long long walk = a.walk_ids ? (unsigned long long)a.walk_ids[w] : a.walk_base + (unsigned long long)w;
+    const unsigned wlo = (unsigned)walk, whi = (unsigned)(walk >> 32);
+    const uint32_t *tape = a.replay ? a.replay + (size_t)w * (n0 + n0 * n1) : nullptr;
+    wave_lds_fence();                        // the previous walk's readers of s_ids / A / H1t are done
+    {
+        const int rc = root >= 0 ? root : 0;
+        const int64_t ra = a.indptr[rc], rb = a.indptr[rc + 1];
+        const uint32_t deg = (uint32_t)(rb - ra);
+        if (root >= 0 && deg == 0 && lane == 0) atomicMax(&a.err[0], root + 1);
+        const bool live = root >= 0 && deg != 0;
+        for (int t = lane; t < n0; t += 64) {
+            const uint32_t rr = tape ? tape[t] : gs::philox4x32_10_x(wlo, whi, 0u, (uint32_t)t, a.key0, a.key1);
+            int32_t v = a.indices[live ? ra + (int64_t)__umulhi(rr, deg) : 0];
+            if (!live) v = -1;
+            hop1[t] = v;
+            if (a.out_hop1) a.out_hop1[(size_t)w * n0 + t] = v;
+        }
+    }
+    wave_lds_fence();
+    {
+        const int total = n0 * n1;
+        for (int base = 0; base < total; base += kChunks * 64) {
+            int32_t p[kChunks];
+            int64_t ca[kChunks], cb[kChunks];
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int t = base + c * 64 + lane;
+                p[c] = t < total ? hop1[t / n1] : -1;
+                const int32_t pc = p[c] >= 0 ? p[c] : 0;
+                ca[c] = a.indptr[pc];
+                cb[c] = a.indptr[pc + 1];
+            }
+            int32_t v[kChunks];
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int t = base + c * 64 + lane;
+                const uint32_t deg = (uint32_t)(cb[c] - ca[c]);
+                uint32_t rr = 0;
+                if (tape) { if (t < total) rr = tape[n0 + t]; }
+                else rr = gs::philox4x32_10_x(wlo, whi, 1u, (uint32_t)t, a.key0, a.key1);
+                const bool live = p[c] >= 0 && deg != 0;
+                if (p[c] >= 0 && deg == 0) atomicMax(&a.err[0], p[c] + 1);
+                v[c] = a.indices[live ? ca[c] + (int64_t)__umulhi(rr, deg) : 0];
+                if (!live) v[c] = -1;
+            }
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int t = base + c * 64 + lane;
+                if (t < total) {
+                    hop2[t] = v[c];
+                    if (a.out_hop2) a.out_hop2[(size_t)w * total + t] = v[c];
+                }
+            }
+        }
+    }
+    wave_lds_fence();
+
+    // ---- layer 0, hop-1 heads (type O; children type T) ---------------------------------
+    constexpr int RP_O = 64 / FOV, NPASS_O = 16 / RP_O;     // own rows per load instruction / passes per tile
+    constexpr int GN_T = 64 / FTV;                           // lane groups summing children rows
+    float4 rootsum = make_float4(0.f, 0.f, 0.f, 0.f);        // partial sum of the hop-1 rows, for the root's mean
+    const int rounds = (n1 + kUnroll - 1) / kUnroll;
+    const int per = (n1 + rounds - 1) / rounds;
+    for (int j0 = 0; j0 < n0; j0 += 16) {
+        const int np = min(16, n0 - j0);
+        float4 own[NPASS_O];
+#pragma unroll
+        for (int pass = 0; pass < NPASS_O; ++pass) {
+            const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
+            long long row = rr < np ? (long long)hop1[j0 + rr] - offO : -1;
+            const bool ok = (unsigned long long)row < (unsigned long long)rowsO;
+            const float4 t = reinterpret_cast<const float4 *>(tableO + (size_t)(ok ? row : 0) * FO)[c];
+            own[pass] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        {
+            const int g = lane / FTV, c = lane % FTV;
+            const float4 *table = reinterpret_cast<const float4 *>(tableT) + c;
+            const float denom = (float)n1;
+            for (int pp = g; pp < 16; pp += GN_T) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pp < np) {
+                    const int32_t *ids = hop2 + (j0 + pp) * n1;
+                    for (int c0 = 0; c0 < n1; c0 += per) {
+                        float4 v[kUnroll];
+                        unsigned okmask = 0;
+#pragma unroll
+                        for (int u = 0; u < kUnroll; ++u) {
+                            const int j = min(c0 + u, n1 - 1);
+                            const long long rw = (long long)ids[j] - offT;
+                            const bool ok = (u < per) && (c0 + u < n1) && ((unsigned long long)rw < (unsigned long long)rowsT);
+                            okmask |= (unsigned)ok << u;
+                            v[u] = table[(ok ? rw : 0) * FTV];
+                        }
+#pragma unroll
+                        for (int u = 0; u < kUnroll; ++u) {
+                            const bool ok = (okmask >> u) & 1;
+                            acc.x += ok ? v[u].x : 0.f; acc.y += ok ? v[u].y : 0.f;
+                            acc.z += ok ? v[u].z : 0.f; acc.w += ok ? v[u].w : 0.f;
+                        }
+                    }
+                    acc.x /= denom; acc.y /= denom; acc.z /= denom; acc.w /= denom;
+                }
+                *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) = acc;
+            }
+        }
+        wave_lds_fence();
+        f32x4 acc_s[NT1], acc_n[NT1];
+#pragma unroll
+        for (int ct = 0; ct < NT1; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_tile<FT, NT1>(A, LDA, W0n_O, wl, r, q, acc_n);
+        wave_lds_fence();
+#pragma unroll
+        for (int pass = 0; pass < NPASS_O; ++pass) {
+            const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
+            *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = own[pass];
+            rootsum.x += own[pass].x; rootsum.y += own[pass].y; rootsum.z += own[pass].z; rootsum.w += own[pass].w;
+        }
+        wave_lds_fence();
+        mma_tile<FO, NT1>(A, LDA, W0s_O, wl, r, q, acc_s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * q + i;
+            if (row < np) {
+                float *dst = H1t + (1 + j0 + row) * LDH;
+#pragma unroll
+                for (int ct = 0; ct < NT1; ++ct) {
+                    dst[ct * 16 + r] = fmaxf(acc_s[ct][i] + b0_O[ct * 16 + r], 0.f);
+                    dst[HH1 + ct * 16 + r] = fmaxf(acc_n[ct][i] + b0_O[HH1 + ct * 16 + r], 0.f);
+                }
+            }
+        }
+        wave_lds_fence();                    // A is rewritten by the next tile
+    }
+
+    // ---- layer 0, the root (type T; its neighbors are the hop-1 heads, type O) -------------
+    {
+        // column chunk c of the sum of the hop-1 rows: add the 64/FOV row groups
+#pragma unroll
+        for (int m = FOV; m < 64; m <<= 1) {
+            rootsum.x += __shfl_xor(rootsum.x, m, 64); rootsum.y += __shfl_xor(rootsum.y, m, 64);
+            rootsum.z += __shfl_xor(rootsum.z, m, 64); rootsum.w += __shfl_xor(rootsum.w, m, 64);
+        }
+        const float d0 = (float)n0;
+        float4 own_root = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            const long long row = (long long)root - offT;
+            const bool ok = root >= 0 && (unsigned long long)row < (unsigned long long)rowsT;
+            if (lane < FTV) {
+                const float4 t = reinterpret_cast<const float4 *>(tableT + (size_t)(ok ? row : 0) * FT)[lane];
+                if (ok) own_root = t;
+            }
+        }
+        if (lane < FOV)
+            *reinterpret_cast<float4 *>(A + 4 * lane) = make_float4(rootsum.x / d0, rootsum.y / d0, rootsum.z / d0, rootsum.w / d0);
+        wave_lds_fence();
+        f32x4 acc_s[NT1], acc_n[NT1];
+#pragma unroll
+        for (int ct = 0; ct < NT1; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_tile<FO, NT1>(A, LDA, W0n_T, wl, r, q, acc_n);
+        wave_lds_fence();
+        if (lane < FTV) *reinterpret_cast<float4 *>(A + 4 * lane) = own_root;
+        wave_lds_fence();
+        mma_tile<FT, NT1>(A, LDA, W0s_T, wl, r, q, acc_s);
+        if (q == 0) {                        // row 0 of D lives in register 0 of lanes 0..15
+#pragma unroll
+            for (int ct = 0; ct < NT1; ++ct) {
+                H1t[ct * 16 + r] = fmaxf(acc_s[ct][0] + b0_T[ct * 16 + r], 0.f);
+                H1t[HH1 + ct * 16 + r] = fmaxf(acc_n[ct][0] + b0_T[HH1 + ct * 16 + r], 0.f);
+            }
+        }
+        wave_lds_fence();
+    }
+
+    // ---- layer 1 on the LDS-resident activations (root only, type T) ---------------------
+    {
+        constexpr int G1 = 64 / H1V;
+        const int g = lane / H1V, c = lane % H1V;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = g; j < n0; j += G1) {
+            const float4 t = *reinterpret_cast<const float4 *>(H1t + (1 + j) * LDH + 4 * c);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+#pragma unroll
+        for (int m = H1V; m < 64; m <<= 1) {
+            s.x += __shfl_xor(s.x, m, 64); s.y += __shfl_xor(s.y, m, 64);
+            s.z += __shfl_xor(s.z, m, 64); s.w += __shfl_xor(s.w, m, 64);
+        }
+        const float d0 = (float)n0;
+        if (lane < H1V) *reinterpret_cast<float4 *>(A + 4 * lane) = make_float4(s.x / d0, s.y / d0, s.z / d0, s.w / d0);
+        wave_lds_fence();
+        f32x4 acc_s[NT2], acc_n[NT2];
+#pragma unroll
+        for (int ct = 0; ct < NT2; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_tile<H1, NT2>(A, LDA, W1n_T, wl, r, q, acc_n);
+        wave_lds_fence();
+        if (lane < H1V) *reinterpret_cast<float4 *>(A + 4 * lane) = *reinterpret_cast<const float4 *>(H1t + 4 * lane);
+        wave_lds_fence();
+        mma_tile<H1, NT2>(A, LDA, W1s_T, wl, r, q, acc_s);
+        float o[2][NT2];
+        float ss = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < NT2; ++ct) {
+            o[0][ct] = acc_s[ct][0] + b1_T[ct * 16 + r];
+            o[1][ct] = acc_n[ct][0] + b1_T[HH2 + ct * 16 + r];
+            ss += o[0][ct] * o[0][ct] + o[1][ct] * o[1][ct];
+        }
+        if (a.normalize) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m, 64);
+            const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+            for (int ct = 0; ct < NT2; ++ct) { o[0][ct] *= inv; o[1][ct] *= inv; }
+        }
+        if (q == 0) {
+            float *dst = a.emb + (size_t)w * H2;
+#pragma unroll
+            for (int ct = 0; ct < NT2; ++ct) {
+                dst[ct * 16 + r] = o[0][ct];
+                dst[HH2 + ct * 16 + r] = o[1][ct];
+            }
+        }
+    }
+}
+
+template <int FU, int FI, int HH1, int HH2>
+__global__ __launch_bounds__(kWaves * 64)
+void sage2_kernel(const Sage2Args a) {
+    using S = Sage2Shape<FU, FI, HH1, HH2>;
+    constexpr int H1 = S::H1, H2 = S::H2, LDA = S::LDA, LDH = S::LDH;
+    extern __shared__ float lds[];
+    // weights in fragment order: layer 0 [user self, user neigh, item self, item neigh], layer 1 likewise
+    float *w0s_u = lds;
+    float *w0n_u = w0s_u + FU * HH1;
+    float *w0s_i = w0n_u + FI * HH1;
+    float *w0n_i = w0s_i + FI * HH1;
+    float *w1s_u = w0n_i + FU * HH1;
+    float *w1n_u = w1s_u + H1 * HH2;
+    float *w1s_i = w1n_u + H1 * HH2;
+    float *w1n_i = w1s_i + H1 * HH2;
+    float *bias = w1n_i + H1 * HH2;          // b0_u[H1] b0_i[H1] b1_u[H2] b1_i[H2]
+    float *wave0 = bias + 2 * H1 + 2 * H2;
+    stage_weight(w0s_u, a.w0_self[0], FU, HH1);
+    stage_weight(w0n_u, a.w0_neigh[0], FI, HH1);
+    stage_weight(w0s_i, a.w0_self[1], FI, HH1);
+    stage_weight(w0n_i, a.w0_neigh[1], FU, HH1);
+    stage_weight(w1s_u, a.w1_self[0], H1, HH2);
+    stage_weight(w1n_u, a.w1_neigh[0], H1, HH2);
+    stage_weight(w1s_i, a.w1_self[1], H1, HH2);
+    stage_weight(w1n_i, a.w1_neigh[1], H1, HH2);
+    for (int i = threadIdx.x; i < 2 * H1 + 2 * H2; i += blockDim.x) {
+        float v = 0.f;
+        if (i < H1) { if (a.b0[0]) v = a.b0[0][i]; }
+        else if (i < 2 * H1) { if (a.b0[1]) v = a.b0[1][i - H1]; }
+        else if (i < 2 * H1 + H2) { if (a.b1[0]) v = a.b1[0][i - 2 * H1]; }
+        else { if (a.b1[1]) v = a.b1[1][i - 2 * H1 - H2]; }
+        bias[i] = v;
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per_wave = 16 * LDA + a.h1_rows * LDH + a.ids_per_wave;
+    float *A = wave0 + (size_t)wave * per_wave;
+    float *H1t = A + 16 * LDA;
+    int32_t *s_ids = reinterpret_cast<int32_t *>(H1t + a.h1_rows * LDH);
+    const long long n_walks = 2 * a.n_pairs;
+    const int n_waves = blockDim.x >> 6;
+    for (long long w = (long long)blockIdx.x * n_waves + wave; w < n_walks; w += (long long)gridDim.x * n_waves) {
+        if (w < a.n_pairs)
+            walk_body<FU, FI, HH1, HH2, LDA, LDH>(a, w, 0, lane, A, H1t, s_ids, w0s_u, w0n_u, w0s_i, w0n_i, w1s_u, w1n_u,
+                                                  bias, bias + H1, bias + 2 * H1);
+        else
+            walk_body<FI, FU, HH1, HH2, LDA, LDH>(a, w, 1, lane, A, H1t, s_ids, w0s_i, w0n_i, w0s_u, w0n_u, w1s_i, w1n_i,
+                                                  bias + H1, bias, bias + 2 * H1 + H2);
+    }
+}
+
+template <int FU, int FI, int HH1, int HH2>
+int launch(const Sage2Args &a, hipStream_t stream) {
+    using S = Sage2Shape<FU, FI, HH1, HH2>;
+    int waves = kWaves;                                  // as many waves per CU as the LDS budget admits
+    while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves) > kLdsMax) waves -= 2;
+    const size_t lds = S::lds_bytes(a.n0, a.n1, waves);
+    if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
+    auto kern = sage2_kernel<FU, FI, HH1, HH2>;
+    static thread_local const void *configured = nullptr;
+    if (lds > 64 * 1024 && configured != (const void *)kern) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+        if (e != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage2_forward: cannot raise the LDS limit: %s", hipGetErrorString(e));
+        configured = (const void *)kern;
+    }
+    const long long n_walks = 2 * a.n_pairs;
+    long long blocks = (n_walks + waves - 1) / waves;
+    if (blocks > 256) blocks = 256;                      // one block per CU, waves loop over walks
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, a);
+    return gs::check_launch("gs_sage2_forward");
+}
+
+// LDS of the smallest block this kernel runs with (4 waves)
+inline size_t sage2_lds(int Fu, int Fi, int H1, int H2, int n0, int n1) {
+    const int fmax = Fu > Fi ? Fu : Fi, kmax = fmax > H1 ? fmax : H1;
+    const int ids = ((n0 + n0 * n1) + 3) & ~3;
+    return (size_t)((Fu + Fi) * H1 + 2 * H1 * H2 + 2 * H1 + 2 * H2 +
+                    4 * (16 * (kmax + 4) + (1 + n0) * (H1 + 4) + ids)) * sizeof(float);
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// (Fu, Fi, H1/2, H2/2) combinations the kernel is instantiated for
+#define GS_SAGE2_CASES(X) \
+    X(64, 64, 16, 16) X(64, 64, 32, 32) X(64, 64, 32, 16) X(64, 64, 16, 32) \
+    X(32, 32, 16, 16) X(32, 32, 32, 32) X(128, 128, 16, 16) X(128, 128, 32, 32) \
+    X(64, 32, 16, 16) X(32, 64, 16, 16)
+
+extern "C" int gs_sage2_supported(int Fu, int Fi, int H1, int H2, int n0, int n1) {
+    if (n0 < 1 || n1 < 1 || n0 > 64 || (long long)n0 * n1 > 4096 || (H1 & 1) || (H2 & 1)) return 0;
+    bool found = false;
+#define GS_X(fu, fi, a1, a2) found = found || (Fu == fu && Fi == fi && H1 == 2 * a1 && H2 == 2 * a2);
+    GS_SAGE2_CASES(GS_X)
+#undef GS_X
+    return found && sage2_lds(Fu, Fi, H1, H2, n0, n1) <= kLdsMax;
+}
+
+extern "C" int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
+                                const float *feat_user, int64_t n_users, int Fu,
+                                const float *feat_item, int64_t n_items, int Fi,
+                                const int32_t *seeds, int64_t n_pairs, int n0, int n1,
+                                uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
+                                const uint32_t *replay,
+                                const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                                const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                                int H1, int H2, int normalize,
+                                float *emb, int32_t *out_hop1, int32_t *out_hop2,
+                                int32_t *err_flag, void *stream) {
+    if (n_pairs < 0) return gs::fail(GS_EINVAL, "gs_sage2_forward: n_pairs=%lld", (long long)n_pairs);
+    if (n_pairs == 0) return GS_OK;
+    if (!indptr || !indices || !feat_user || !feat_item || !seeds || !emb || !err_flag ||
+        !l0_user || !l0_item || !l1_user || !l1_item)
+        return gs::fail(GS_EINVAL, "gs_sage2_forward: null pointer argument");
+    const gs_sage_weights *ws[4] = {l0_user, l0_item, l1_user, l1_item};
+    for (int i = 0; i < 4; ++i)
+        if (!ws[i]->w_self || !ws[i]->w_neigh) return gs::fail(GS_EINVAL, "gs_sage2_forward: weight set %d has a null matrix", i);
+    if (n_users < 1 || n_items < 1 || n_nodes != n_users + n_items)
+        return gs::fail(GS_EINVAL, "gs_sage2_forward: n_nodes=%lld must equal n_users + n_items = %lld + %lld",
+                        (long long)n_nodes, (long long)n_users, (long long)n_items);
+    if (!aligned16(feat_user) || !aligned16(feat_item))
+        return gs::fail(GS_EINVAL, "gs_sage2_forward: feature tables must be 16-byte aligned");
+    if (!gs_sage2_supported(Fu, Fi, H1, H2, n0, n1))
+        return gs::fail(GS_ELIMIT, "gs_sage2_forward: shape Fu=%d Fi=%d H1=%d H2=%d fan-outs [%d,%d] is outside this kernel's "
+                                   "range; use gs_sample + gs_sage_fused_fwd", Fu, Fi, H1, H2, n0, n1);
+    Sage2Args a{};
+    a.indptr = indptr; a.indices = indices; a.n_nodes = n_nodes;
+    a.feat[0] = feat_user; a.feat[1] = feat_item; a.n_rows[0] = n_users; a.n_rows[1] = n_items;
+    a.seeds = seeds; a.n_pairs = n_pairs; a.n0 = n0; a.n1 = n1;
+    a.key0 = (unsigned)rng_seed; a.key1 = (unsigned)(rng_seed >> 32); a.walk_base = walk_id_base;
+    a.walk_ids = walk_ids; a.replay = replay;
+    a.w0_self[0] = l0_user->w_self; a.w0_neigh[0] = l0_user->w_neigh; a.b0[0] = l0_user->bias;
+    a.w0_self[1] = l0_item->w_self; a.w0_neigh[1] = l0_item->w_neigh; a.b0[1] = l0_item->bias;
+    a.w1_self[0] = l1_user->w_self; a.w1_neigh[0] = l1_user->w_neigh; a.b1[0] = l1_user->bias;
+    a.w1_self[1] = l1_item->w_self; a.w1_neigh[1] = l1_item->w_neigh; a.b1[1] = l1_item->bias;
+    a.normalize = normalize; a.emb = emb; a.out_hop1 = out_hop1; a.out_hop2 = out_hop2; a.err = err_flag;
+    a.ids_per_wave = ((n0 + n0 * n1) + 3) & ~3;
+    a.h1_rows = 1 + n0;
+    hipStream_t s = (hipStream_t)stream;
+    const int hh1 = H1 / 2, hh2 = H2 / 2;
+#define GS_X(fu, fi, a1, a2) if (Fu == fu && Fi == fi && hh1 == a1 && hh2 == a2) return launch<fu, fi, a1, a2>(a, s);
+    GS_SAGE2_CASES(GS_X)
+#undef GS_X
+    return gs::fail(GS_ELIMIT, "gs_sage2_forward: no instantiation for Fu=%d Fi=%d H1=%d H2=%d", Fu, Fi, H1, H2);
+}

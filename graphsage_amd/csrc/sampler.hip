@@ -24,6 +24,7 @@ struct SampleParams {
 };
 
 constexpr int kWavesPerBlock = 4;
+constexpr int kChunks = 4;
 
 __global__ __launch_bounds__(kWavesPerBlock * 64)
 void sample_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
@@ -56,23 +57,42 @@ void sample_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict
         int32_t *cur = (h & 1) ? buf1 : buf0;               // ids of hop h
         const bool keep = h + 1 < P.n_hops;
         int32_t *dst = P.out[h] + (size_t)w * total;
-        for (int t = lane; t < total; t += 64) {
-            const int32_t p = (h == 0) ? root : par[t / k];
-            int32_t v = -1;
-            if (p >= 0) {
-                const int64_t a = indptr[p];
-                const int64_t b = indptr[p + 1];
-                const uint32_t deg = (uint32_t)(b - a);
-                if (deg == 0) {
-                    atomicMax(&err[0], p + 1);
-                } else {
-                    const uint32_t r = tape ? tape[P.off[h] + t]
-                                            : gs::philox4x32_10_x(wlo, whi, (uint32_t)h, (uint32_t)t, key0, key1);
-                    v = indices[a + (int64_t)__umulhi(r, deg)];
+        // kChunks * 64 slots per pass: all row-bound loads of a pass are issued before the first
+        // neighbor load, so a pass costs two dependent memory round trips however many slots it has
+        for (int base = 0; base < total; base += kChunks * 64) {
+            int32_t p[kChunks];
+            int64_t a[kChunks], b[kChunks];
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int t = base + c * 64 + lane;
+                p[c] = -1;
+                if (t < total) p[c] = (h == 0) ? root : par[t / k];
+                const int32_t pc = p[c] >= 0 ? p[c] : 0;    // node 0 stands in for dead slots
+                a[c] = indptr[pc];
+                b[c] = indptr[pc + 1];
+            }
+            int32_t v[kChunks];
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int t = base + c * 64 + lane;
+                const uint32_t deg = (uint32_t)(b[c] - a[c]);
+                uint32_t r = 0;
+                if (tape) { if (t < total) r = tape[P.off[h] + t]; }
+                else r = gs::philox4x32_10_x(wlo, whi, (uint32_t)h, (uint32_t)t, key0, key1);
+                const bool live = p[c] >= 0 && deg != 0;
+                if (p[c] >= 0 && deg == 0) atomicMax(&err[0], p[c] + 1);
+                const int64_t pos = live ? a[c] + (int64_t)__umulhi(r, deg) : 0;
+                v[c] = indices[pos];
+                if (!live) v[c] = -1;
+            }
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int t = base + c * 64 + lane;
+                if (t < total) {
+                    dst[t] = v[c];
+                    if (keep) cur[t] = v[c];
                 }
             }
-            dst[t] = v;
-            if (keep) cur[t] = v;
         }
         // make this hop's LDS writes visible to the other lanes of the wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -23,7 +23,7 @@ _TYPES = ('user', 'item')
 
 
 class SageForwardEngine:
-    def __init__(self, graph, model, batch_size, use_fused=True):
+    def __init__(self, graph, model, batch_size, use_fused=True, walk_kernel=True):
         self.graph = graph
         self.model = model.build()
         self.fanouts = [int(n) for n in model.n_samples]
@@ -71,6 +71,11 @@ class SageForwardEngine:
         self.use_fused = use_fused
         self.fused_layers = [self._fused_ok(layer) and use_fused for layer in range(self.n_hops)]
         self._fused_calls = {}
+        # two hops: the whole forward pass as one kernel, one wavefront per walk
+        self.walk_kernel = bool(use_fused and walk_kernel and self.n_hops == 2 and kernels.sage2_supported(
+            f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'], *self.fanouts))
+        self._walk_call = None
+        self.emb_all = torch.empty((2 * b, model.dims[-1]['user']), dtype=torch.float32, device=device)
 
     # -- pieces ---------------------------------------------------------------
     def _slot_ids(self, seeds, h, side):
@@ -206,7 +211,27 @@ class SageForwardEngine:
             self._run_fused_layer(layer, seeds)
         return self.emb['user'], self.emb['item']
 
+    def forward_walks(self, seeds, walk_ids=None, rng_seed=0, replay=None):
+        """sample + both layers + l2norm in one launch (two-hop models)."""
+        if self._walk_call is None:
+            m = self.model
+            weights = {(l, t): (m._aggs[l][t].w_self, m._aggs[l][t].w_neigh, m._aggs[l][t].bias)
+                       for l in (0, 1) for t in _TYPES}
+            self._walk_call = kernels.Sage2Call(self.indptr, self.indices, self.tables['user'][0],
+                                                self.tables['item'][0], self.fanouts, weights,
+                                                m.normalize == "l2", self.batch, emb=self.emb_all)
+        if self.probes is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._walk_call.run(seeds, self.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
+        if self.probes is not None:
+            e1.record()
+            self.probes.append((e0, e1))
+        return self.emb_all[:self.batch], self.emb_all[self.batch:]
+
     def forward(self, seeds, walk_ids=None, rng_seed=0, replay=None):
+        if self.walk_kernel:
+            return self.forward_walks(seeds, walk_ids, rng_seed, replay)
         self.sample(seeds, walk_ids, rng_seed, replay)
         if self.use_fused and all(self.fused_layers):
             return self.aggregate_fused(seeds)
@@ -214,6 +239,8 @@ class SageForwardEngine:
 
     # -- accounting for the benchmark --------------------------------------------
     def dominant_name(self):
+        if self.walk_kernel:
+            return "sage2_kernel (sample + both layers + l2norm, one wavefront per walk)"
         if self.use_fused and all(self.fused_layers):
             return "sage_fused_kernel (layer 0: gather + neighbor mean + projection, one launch per node type)"
         return "gather_mean_kernel (deepest hop: rows summed as fetched)"
@@ -224,6 +251,14 @@ class SageForwardEngine:
         parent (average of the user-table and item-table launches)."""
         b, h = self.batch, self.n_hops - 1
         f = self.graph.node_feature_sizes
+        if self.walk_kernel:
+            # the one-kernel forward: CSR reads as the sampler's accounting (without the id
+            # round trip), every sampled node's feature row once, one embedding row per root
+            sampler, agg = self.algorithmic_bytes()
+            samples = 2 * sum(self.sizes[1:])
+            rows = sum(b * self.sizes[hh] * f[_TYPES[(side + hh) % 2]] * 4
+                       for hh in range(self.n_hops + 1) for side in range(2))
+            return (sampler - b * 4 * samples) + rows + 2 * b * self.model.dims[-1]['user'] * 4
         if self.use_fused and all(self.fused_layers):
             # fused layer 0, one launch per head type: head + child ids read, one feature row per
             # head and per child read, one output row per head written
@@ -251,6 +286,8 @@ class SageForwardEngine:
         with open(path) as fh:
             rec = json.load(fh)
         name = "sage_fused_kernel" if self.use_fused and all(self.fused_layers) else "gather_mean_kernel"
+        if self.walk_kernel:
+            name = "sage2_kernel"
         key = "%s/B%d/%s" % (name, self.batch, 'x'.join(str(n) for n in self.fanouts))
         return rec.get(key)
 

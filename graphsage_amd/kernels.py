@@ -292,3 +292,85 @@ def sage_fused(feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_n
         out = torch.empty((rows, 2 * w_self.shape[1]), dtype=torch.float32, device=feat_self.device)
     return FusedLayerCall(feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_neigh, bias, act,
                           normalize, out, save_self, save_mean).run()
+
+
+def sage2_supported(fu, fi, h1, h2, n0, n1):
+    return bool(load().gs_sage2_supported(int(fu), int(fi), int(h1), int(h2), int(n0), int(n1)))
+
+
+class Sage2Call:
+    """A prepared ``gs_sage2_forward`` call (whole two-hop forward, one kernel).
+
+    ``weights`` = {(layer, node_type): (w_self, w_neigh, bias or None)} for layers
+    0, 1 and node types 'user', 'item'.
+    """
+
+    def __init__(self, indptr, indices, feat_user, feat_item, fanouts, weights, normalize, n_pairs,
+                 emb=None, keep_ids=False):
+        lib = load()
+        _dev(indptr, torch.int64, 'indptr', 1)
+        _dev(indices, torch.int32, 'indices', 1)
+        _dev(feat_user, torch.float32, 'feat_user', 2)
+        _dev(feat_item, torch.float32, 'feat_item', 2)
+        if len(fanouts) != 2:
+            raise ValueError("the one-kernel forward covers exactly two hops")
+        n0, n1 = int(fanouts[0]), int(fanouts[1])
+        nu, fu = feat_user.shape
+        ni, fi = feat_item.shape
+        if indptr.numel() != nu + ni + 1:
+            raise ValueError("indptr must have n_users + n_items + 1 entries")
+        self._w = []
+        dims = {}
+        for layer in (0, 1):
+            for t in ('user', 'item'):
+                w_self, w_neigh, bias = weights[(layer, t)]
+                _dev(w_self, torch.float32, 'w_self', 2)
+                _dev(w_neigh, torch.float32, 'w_neigh', 2)
+                if bias is not None:
+                    _dev(bias, torch.float32, 'bias', 1)
+                dims[(layer, t)] = (w_self.shape[0], w_neigh.shape[0], 2 * w_self.shape[1])
+                if w_neigh.shape[1] != w_self.shape[1] or (bias is not None and bias.numel() != 2 * w_self.shape[1]):
+                    raise ValueError("inconsistent weight shapes for layer %d, %s" % (layer, t))
+                self._w.append(_lib.SageWeights(ptr(w_self), ptr(w_neigh), ptr(bias)))
+        h1, h2 = dims[(0, 'user')][2], dims[(1, 'user')][2]
+        want = {(0, 'user'): (fu, fi, h1), (0, 'item'): (fi, fu, h1), (1, 'user'): (h1, h1, h2), (1, 'item'): (h1, h1, h2)}
+        if dims != want:
+            raise ValueError("weight shapes %s do not fit the model %s" % (dims, want))
+        if not lib.gs_sage2_supported(fu, fi, h1, h2, n0, n1):
+            raise _lib.GsageError("the one-kernel forward does not cover Fu=%d Fi=%d H=[%d,%d] fan-outs [%d,%d]" %
+                                  (fu, fi, h1, h2, n0, n1))
+        dev = indptr.device
+        self.n_pairs = int(n_pairs)
+        self.emb = emb if emb is not None else torch.empty((2 * self.n_pairs, h2), dtype=torch.float32, device=dev)
+        _dev(self.emb, torch.float32, 'emb', 2)
+        if tuple(self.emb.shape) != (2 * self.n_pairs, h2):
+            raise ValueError("emb must be (%d, %d)" % (2 * self.n_pairs, h2))
+        self.hop1 = torch.empty((2 * self.n_pairs, n0), dtype=torch.int32, device=dev) if keep_ids else None
+        self.hop2 = torch.empty((2 * self.n_pairs, n0 * n1), dtype=torch.int32, device=dev) if keep_ids else None
+        self._lib = lib
+        self._keep = [indptr, indices, feat_user, feat_item, weights]
+        self._tape_len = n0 + n0 * n1
+        self._fixed_a = (ptr(indptr), ptr(indices), nu + ni, ptr(feat_user), nu, fu, ptr(feat_item), ni, fi)
+        self._fixed_b = (ctypes.byref(self._w[0]), ctypes.byref(self._w[1]), ctypes.byref(self._w[2]),
+                         ctypes.byref(self._w[3]), h1, h2, int(bool(normalize)), ptr(self.emb), ptr(self.hop1),
+                         ptr(self.hop2))
+        self._n0, self._n1 = n0, n1
+
+    def run(self, seeds, err_flag, rng_seed=0, walk_id_base=0, walk_ids=None, replay=None):
+        _dev(seeds, torch.int32, 'seeds', 1)
+        _dev(err_flag, torch.int32, 'err_flag', 1)
+        if seeds.numel() != 2 * self.n_pairs:
+            raise ValueError("seeds must hold %d roots" % (2 * self.n_pairs))
+        if walk_ids is not None:
+            _dev(walk_ids, torch.int64, 'walk_ids', 1)
+            if walk_ids.numel() != seeds.numel():
+                raise ValueError("walk_ids must have one entry per seed")
+        if replay is not None:
+            _dev(replay, torch.int32, 'replay', 1)
+            if replay.numel() != seeds.numel() * self._tape_len:
+                raise ValueError("replay tape has the wrong length")
+        check(self._lib.gs_sage2_forward(*self._fixed_a, ptr(seeds), self.n_pairs, self._n0, self._n1,
+                                         int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(walk_id_base) & 0xFFFFFFFFFFFFFFFF,
+                                         ptr(walk_ids), ptr(replay), *self._fixed_b, ptr(err_flag), stream_handle()),
+              'gs_sage2_forward')
+        return self.emb

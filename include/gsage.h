@@ -186,6 +186,44 @@ int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64
                       int H, int act, int normalize,
                       float *out, float *save_self, float *save_mean, void *stream);
 
+/*
+ * The whole two-hop forward pass in one kernel, one wavefront per walk: sampling
+ * (as gs_sample), both aggregator layers (as gs_sage_fused_fwd) and the l2
+ * normalisation, for the reference's own model depth (its generator and type
+ * adjacency list are written for exactly two hops, generator.py:239-244,
+ * 339-345; layers per models.py:146-190).  Only the embeddings are written:
+ *   emb[w, :]  w < n_pairs: user embedding of pair w; w >= n_pairs: item
+ *              embedding of pair w - n_pairs                (device float [2*n_pairs, H2])
+ * seeds are the 2*n_pairs roots (user heads, then item heads); users are ids
+ * [0, n_users), items [n_users, n_users + n_items) = n_nodes.  Draws, replay
+ * tape and err_flag exactly as gs_sample with fanouts {n0, n1}.  out_hop1 /
+ * out_hop2 (nullable) receive the sampled ids ([2*n_pairs, n0] and
+ * [2*n_pairs, n0*n1]) when the caller wants them.
+ * Weight sets are per (layer, head node type), shaped as Aggregator.build makes
+ * them (utils.py:72-89); bias may be NULL.
+ * gs_sage2_supported() != 0 tells whether this build covers the shape; if not,
+ * GS_ELIMIT is returned and gs_sample + gs_sage_fused_fwd (or the unfused
+ * entry points) compute the same thing.
+ */
+typedef struct gs_sage_weights {
+    const float *w_self;    /* [F_self,  H/2] */
+    const float *w_neigh;   /* [F_neigh, H/2] */
+    const float *bias;      /* [H] or NULL    */
+} gs_sage_weights;
+
+int gs_sage2_supported(int Fu, int Fi, int H1, int H2, int n0, int n1);
+int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
+                     const float *feat_user, int64_t n_users, int Fu,
+                     const float *feat_item, int64_t n_items, int Fi,
+                     const int32_t *seeds, int64_t n_pairs, int n0, int n1,
+                     uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
+                     const uint32_t *replay,
+                     const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                     const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                     int H1, int H2, int normalize,
+                     float *emb, int32_t *out_hop1, int32_t *out_hop2,
+                     int32_t *err_flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -487,7 +487,7 @@ def test_engine_fused_and_unfused_match_model_and_oracle(cuda, ns, sizes, fu, fi
     seeds = torch.tensor([l[0] for l in links] + [l[1] for l in links], dtype=torch.int32, device=cuda)
     walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda)
 
-    eng_f = SageForwardEngine(g, model, b, use_fused=True)
+    eng_f = SageForwardEngine(g, model, b, use_fused=True, walk_kernel=False)
     eng_u = SageForwardEngine(g, model, b, use_fused=False)
     fused_shapes = fu % 32 == 0 and fi % 32 == 0
     assert all(eng_f.fused_layers) == fused_shapes
@@ -516,3 +516,86 @@ def test_engine_fused_and_unfused_match_model_and_oracle(cuda, ns, sizes, fu, fi
     for k in range(2):
         close(o1[k], o2[k], scale=1.0)
     assert not torch.equal(o1[0], out_f[0])
+
+
+# -------------------------------------------- whole forward in one kernel ----
+
+@pytest.mark.parametrize('case', [0, 2, 3, 5])
+def test_walk_kernel_replay_against_reference_batches(golden, cuda, case):
+    """gs_sage2_forward on replayed draws: sampled ids equal the reference's walks
+    bit for bit, embeddings equal the float64 oracle applied to the reference
+    generator's own feature arrays (graph features padded to a supported width)."""
+    arrays, meta = golden
+    info = meta['replay'][case]
+    key, ns, b = info['key'], info['num_samples'], info['batch']
+    feats, nodes, edges = golden_graph_parts(arrays, info['graph'])
+    pad = lambda a, f: np.concatenate([a, np.zeros((a.shape[0], f - a.shape[1]), np.float32)], axis=1)
+    feats = {'user': pad(feats['user'], 32), 'item': pad(feats['item'], 32)}
+    g = ga.Graph(feats, nodes, edges)
+    links = arrays[key + '_links']
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=1)
+    model = ga.GraphSAGE([32, 32], gen, seed=13).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.1, 0.1)
+    dev = g.device_tensors()
+    weights = {(l, t): (model._aggs[l][t].w_self, model._aggs[l][t].w_neigh, model._aggs[l][t].bias)
+               for l in (0, 1) for t in ('user', 'item')}
+    call = kernels.Sage2Call(dev['indptr'], dev['indices'], dev['user'], dev['item'], ns, weights, True, b,
+                             keep_ids=True)
+    seeds = torch.from_numpy(np.concatenate([links[:, 0], links[:, 1]]).astype(np.int32)).to(cuda)
+    tape = torch.from_numpy(arrays[key + '_tape'].view(np.int32)).to(cuda)
+    err = torch.zeros(2, dtype=torch.int32, device=cuda)
+    emb = call.run(seeds, err, replay=tape)
+    assert err.tolist() == [0, 0]
+    np.testing.assert_array_equal(call.hop1.cpu().numpy(), arrays[key + '_hop1'])
+    np.testing.assert_array_equal(call.hop2.cpu().numpy(), arrays[key + '_hop2'])
+    xin = [torch.from_numpy(pad(arrays[key + '_x%d' % i].reshape(-1, arrays[key + '_x%d' % i].shape[2]), 32)
+                            .reshape(b, -1, 32)).double() for i in range(6)]
+    plan = omodel.LayerPlan([32, 32], ns, g.node_feature_sizes)
+    want = omodel.forward(plan, _oracle_model(model, plan), xin)
+    close(emb[:b], want[0], scale=1.0)
+    close(emb[b:], want[1], scale=1.0)
+
+
+@pytest.mark.parametrize('ns,sizes,fu,fi', [([25, 10], [32, 32], 64, 64), ([8, 4], [64, 64], 64, 64),
+                                            ([10, 5], [32, 32], 64, 32), ([33, 7], [32, 32], 128, 128),
+                                            ([64, 3], [32, 64], 64, 64), ([3, 70], [32, 32], 32, 32)])
+def test_walk_kernel_matches_layered_engine_and_oracle(cuda, ns, sizes, fu, fi):
+    from graphsage_amd.engine import SageForwardEngine
+    rng = np.random.default_rng(7)
+    nu, ni, b = 300, 60, 37
+    u = np.concatenate([rng.integers(0, nu, 2500), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 2500), np.arange(nu) % ni]) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, fu)).astype(np.float32),
+             'item': rng.standard_normal((ni, fi)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=2)
+    model = ga.GraphSAGE(sizes, gen, seed=3).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.1, 0.1)
+    links = [(int(e[0, i]), int(e[1, i])) for i in range(b)]
+    seeds = torch.tensor([l[0] for l in links] + [l[1] for l in links], dtype=torch.int32, device=cuda)
+    walk_ids = (torch.arange(2 * b, dtype=torch.int64, device=cuda) * 3 + (1 << 35))
+    eng_w = SageForwardEngine(g, model, b)
+    eng_l = SageForwardEngine(g, model, b, walk_kernel=False)
+    assert eng_w.walk_kernel and not eng_l.walk_kernel
+    out_w = [x.clone() for x in eng_w.forward(seeds, walk_ids, rng_seed=4242)]
+    out_l = [x.clone() for x in eng_l.forward(seeds, walk_ids, rng_seed=4242)]
+    assert eng_w.err_flag.tolist() == [0, 0]
+    hops = [h.cpu().numpy().astype(np.int64) for h in eng_l.hops]
+    xin = ogen.sample_features_fast({k: v.astype(np.float64) for k, v in feats.items()}, nu, links, hops)
+    plan = omodel.LayerPlan(sizes, ns, g.node_feature_sizes)
+    want = omodel.forward(plan, _oracle_model(model, plan), [torch.from_numpy(x) for x in xin])
+    for k in range(2):
+        close(out_w[k], want[k], scale=1.0)
+        close(out_l[k], want[k], scale=1.0)
+    # isolated node / bad seed handling inside the one-kernel path
+    bad = seeds.clone()
+    bad[3] = nu + ni + 5
+    eng_w.err_flag.zero_()
+    eng_w.forward(bad, walk_ids, rng_seed=1)
+    assert eng_w.err_flag.tolist()[1] == 1
