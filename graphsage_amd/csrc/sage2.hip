@@ -32,9 +32,10 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kWaves = 12;               // most waves per block: one block per CU, 3 waves per SIMD
+constexpr int kWaves = 16;               // most waves per block: one block per CU, 4 waves per SIMD
 constexpr int kUnroll = 10;              // row loads in flight per lane in the mean phase
 constexpr int kChunks = 4;               // 64-slot chunks sampled per pass
+constexpr int kHeads = 1;                // heads per lane group whose row loads are issued together
 constexpr size_t kLdsMax = 160 * 1024;
 
 struct Sage2Args {
@@ -56,6 +57,38 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// A feature table as the gather loops see it.  BUF: a 128-bit buffer descriptor (tables below
+// 4 GiB): one 32-bit offset register per load and the hardware range check returns zeros for an
+// out-of-range offset, so an invalid row costs one select on the offset and nothing after the
+// load.  !BUF: plain 64-bit global loads with the zeroing done by a select on the data.
+template <bool BUF>
+struct RowTable {
+    __amdgpu_buffer_rsrc_t rs;
+    const char *base;
+    long long rows;
+
+    __device__ __forceinline__ void init(const float *p, long long n_rows, int row_bytes) {
+        base = reinterpret_cast<const char *>(p);
+        rows = n_rows;
+        if (BUF) rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)(unsigned)(n_rows * row_bytes), 0x00020000);
+    }
+    // 16 bytes at byte column `col` of row `row` (row = node id - type offset, computed in 32
+    // bits: ids and row counts are below 2^31, so a negative or too large row fails the unsigned
+    // compare); zeros when `want` is false or the row is outside the table
+    __device__ __forceinline__ float4 load(bool want, unsigned row, unsigned col, int row_bytes) const {
+        const bool ok = want && row < (unsigned)rows;
+        if (BUF) {
+            const unsigned off = ok ? row * (unsigned)row_bytes + col : 0xFFFFFFF0u;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+            return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+        const float4 t = *reinterpret_cast<const float4 *>(base + (size_t)(ok ? row : 0u) * row_bytes + col);
+        return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
 
 // D[16 x 16*NT] += A[16 x K] . W[K x 16*NT]; A in LDS (row stride lda), W in fragment order.
 template <int K, int NT>
@@ -88,12 +121,12 @@ struct Sage2Shape {
     static constexpr int H1 = 2 * HH1, H2 = 2 * HH2;
     static constexpr int KMAX = FMAX > H1 ? FMAX : H1;
     static constexpr int LDA = KMAX + 4;
-    static constexpr int LDH = H1 + 4;
+    static constexpr int LDH = H1;
     static constexpr int NT1 = HH1 / 16, NT2 = HH2 / 16;
     // fragment floats: layer 0 per type (self: own width, neigh: other width), layer 1 per type (2 x H1)
     static constexpr int W0_FLOATS = 2 * (FU + FI) * HH1;
-    static constexpr int W1_FLOATS = 4 * H1 * HH2;
-    static constexpr int B_FLOATS = 2 * H1 + 2 * H2;
+    static constexpr int W1_FLOATS = 2 * H1 * HH2;          // a block serves one side: one layer-1 weight set
+    static constexpr int B_FLOATS = 2 * H1 + H2;
     static size_t lds_bytes(int n0, int n1, int waves) {
         const int ids = ((n0 + n0 * n1) + 3) & ~3;
         const int h1_rows = 1 + n0;
@@ -102,8 +135,10 @@ struct Sage2Shape {
 };
 
 // One walk.  FT / FO: feature widths of the root's type and of the other type.
-template <int FT, int FO, int HH1, int HH2, int LDA, int LDH>
+template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF>
 __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int side, int lane,
+                                          int32_t root, int64_t ra, int64_t rb,
+                                          int32_t next_root, int64_t &next_ra, int64_t &next_rb,
                                           float *A, float *H1t, int32_t *s_ids,
                                           const float *W0s_T, const float *W0n_T, const float *W0s_O, const float *W0n_O,
                                           const float *W1s_T, const float *W1n_T,
@@ -112,26 +147,21 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     constexpr int FTV = FT / 4, FOV = FO / 4, H1V = H1 / 4;
     const int r = lane & 15, q = lane >> 4;
     const int n0 = a.n0, n1 = a.n1;
-    const float *tableT = a.feat[side], *tableO = a.feat[1 - side];
-    const long long rowsT = a.n_rows[side], rowsO = a.n_rows[1 - side];
-    const long long offT = side ? a.n_rows[0] : 0, offO = side ? 0 : a.n_rows[0];
+    RowTable<BUF> tabT, tabO;
+    tabT.init(a.feat[side], a.n_rows[side], FT * 4);
+    tabO.init(a.feat[1 - side], a.n_rows[1 - side], FO * 4);
+    const int offT = side ? (int)a.n_rows[0] : 0, offO = side ? 0 : (int)a.n_rows[0];
     int32_t *hop1 = s_ids, *hop2 = s_ids + n0;
     int wl = lane;
     asm volatile("" : "+v"(wl));            // keeps the weight-fragment reads inside the walk loop
 
     // ---- sampling ---------------------------------------------------------------
-    int32_t root = a.seeds[w];
-    if ((unsigned long long)(long long)root >= (unsigned long long)a.n_nodes) {
-        if (lane == 0) atomicMax(&a.err[1], 1);
-        root = -1;
-    }
+    if (root < 0 && lane == 0) atomicMax(&a.err[1], 1);    // the caller maps out-of-range roots to -1
     const unsigned long long walk = a.walk_ids ? (unsigned long long)a.walk_ids[w] : a.walk_base + (unsigned long long)w;
     const unsigned wlo = (unsigned)walk, whi = (unsigned)(walk >> 32);
     const uint32_t *tape = a.replay ? a.replay + (size_t)w * (n0 + n0 * n1) : nullptr;
     wave_lds_fence();                        // the previous walk's readers of s_ids / A / H1t are done
     {
-        const int rc = root >= 0 ? root : 0;
-        const int64_t ra = a.indptr[rc], rb = a.indptr[rc + 1];
         const uint32_t deg = (uint32_t)(rb - ra);
         if (root >= 0 && deg == 0 && lane == 0) atomicMax(&a.err[0], root + 1);
         const bool live = root >= 0 && deg != 0;
@@ -181,6 +211,11 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         }
     }
     wave_lds_fence();
+    {   // row bounds of the NEXT walk's root: in flight while this walk gathers
+        const int32_t nr = next_root >= 0 ? next_root : 0;
+        next_ra = a.indptr[nr];
+        next_rb = a.indptr[nr + 1];
+    }
 
     // ---- layer 0, hop-1 heads (type O; children type T) ---------------------------------
     constexpr int RP_O = 64 / FOV, NPASS_O = 16 / RP_O;     // own rows per load instruction / passes per tile
@@ -194,40 +229,49 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
 #pragma unroll
         for (int pass = 0; pass < NPASS_O; ++pass) {
             const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
-            long long row = rr < np ? (long long)hop1[j0 + rr] - offO : -1;
-            const bool ok = (unsigned long long)row < (unsigned long long)rowsO;
-            const float4 t = reinterpret_cast<const float4 *>(tableO + (size_t)(ok ? row : 0) * FO)[c];
-            own[pass] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int32_t id = hop1[j0 + min(rr, np - 1)];
+            own[pass] = tabO.load(rr < np, (unsigned)(id - offO), (unsigned)c * 16u, FO * 4);
         }
         {
+            // kHeads heads per lane group and iteration: their row loads are all issued before
+            // the first add, which is what keeps enough bytes in flight per wave
             const int g = lane / FTV, c = lane % FTV;
-            const float4 *table = reinterpret_cast<const float4 *>(tableT) + c;
+            const unsigned col = (unsigned)c * 16u;
             const float denom = (float)n1;
-            for (int pp = g; pp < 16; pp += GN_T) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pp < np) {
-                    const int32_t *ids = hop2 + (j0 + pp) * n1;
-                    for (int c0 = 0; c0 < n1; c0 += per) {
-                        float4 v[kUnroll];
-                        unsigned okmask = 0;
+            for (int pp0 = g; pp0 < 16; pp0 += kHeads * GN_T) {
+                float4 acc[kHeads];
+#pragma unroll
+                for (int hd = 0; hd < kHeads; ++hd) acc[hd] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c0 = 0; c0 < n1; c0 += per) {
+                    float4 v[kHeads][kUnroll];
+#pragma unroll
+                    for (int hd = 0; hd < kHeads; ++hd) {
+                        const int pp = pp0 + hd * GN_T;
+                        const int32_t *ids = hop2 + (j0 + min(pp, np - 1)) * n1;
+                        int32_t cid[kUnroll];                 // all id reads first: one LDS wait per batch
+#pragma unroll
+                        for (int u = 0; u < kUnroll; ++u) cid[u] = ids[min(c0 + u, n1 - 1)];
 #pragma unroll
                         for (int u = 0; u < kUnroll; ++u) {
-                            const int j = min(c0 + u, n1 - 1);
-                            const long long rw = (long long)ids[j] - offT;
-                            const bool ok = (u < per) && (c0 + u < n1) && ((unsigned long long)rw < (unsigned long long)rowsT);
-                            okmask |= (unsigned)ok << u;
-                            v[u] = table[(ok ? rw : 0) * FTV];
-                        }
-#pragma unroll
-                        for (int u = 0; u < kUnroll; ++u) {
-                            const bool ok = (okmask >> u) & 1;
-                            acc.x += ok ? v[u].x : 0.f; acc.y += ok ? v[u].y : 0.f;
-                            acc.z += ok ? v[u].z : 0.f; acc.w += ok ? v[u].w : 0.f;
+                            const bool want = (pp < np) && (u < per) && (c0 + u < n1);
+                            v[hd][u] = tabT.load(want, (unsigned)(cid[u] - offT), col, FT * 4);
                         }
                     }
-                    acc.x /= denom; acc.y /= denom; acc.z /= denom; acc.w /= denom;
+#pragma unroll
+                    for (int hd = 0; hd < kHeads; ++hd)
+#pragma unroll
+                        for (int u = 0; u < kUnroll; ++u) {
+                            acc[hd].x += v[hd][u].x; acc[hd].y += v[hd][u].y;
+                            acc[hd].z += v[hd][u].z; acc[hd].w += v[hd][u].w;
+                        }
                 }
-                *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) = acc;
+#pragma unroll
+                for (int hd = 0; hd < kHeads; ++hd) {
+                    const int pp = pp0 + hd * GN_T;
+                    if (pp < 16)
+                        *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) =
+                            make_float4(acc[hd].x / denom, acc[hd].y / denom, acc[hd].z / denom, acc[hd].w / denom);
+                }
             }
         }
         wave_lds_fence();
@@ -270,12 +314,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         const float d0 = (float)n0;
         float4 own_root = make_float4(0.f, 0.f, 0.f, 0.f);
         {
-            const long long row = (long long)root - offT;
-            const bool ok = root >= 0 && (unsigned long long)row < (unsigned long long)rowsT;
-            if (lane < FTV) {
-                const float4 t = reinterpret_cast<const float4 *>(tableT + (size_t)(ok ? row : 0) * FT)[lane];
-                if (ok) own_root = t;
-            }
+            own_root = tabT.load(root >= 0 && lane < FTV, (unsigned)(root - offT), (unsigned)(lane % FTV) * 16u, FT * 4);
         }
         if (lane < FOV)
             *reinterpret_cast<float4 *>(A + 4 * lane) = make_float4(rootsum.x / d0, rootsum.y / d0, rootsum.z / d0, rootsum.w / d0);
@@ -349,37 +388,35 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     }
 }
 
-template <int FU, int FI, int HH1, int HH2>
+template <int FU, int FI, int HH1, int HH2, bool BUF>
 __global__ __launch_bounds__(kWaves * 64)
 void sage2_kernel(const Sage2Args a) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     constexpr int H1 = S::H1, H2 = S::H2, LDA = S::LDA, LDH = S::LDH;
     extern __shared__ float lds[];
-    // weights in fragment order: layer 0 [user self, user neigh, item self, item neigh], layer 1 likewise
+    // Even blocks take the walks rooted at user heads, odd blocks those rooted at item heads, so
+    // a block needs one layer-1 weight set.  Weights in fragment order: layer 0 [user self, user
+    // neigh, item self, item neigh], layer 1 [self, neigh] of the block's root type.
+    const int side = blockIdx.x & 1;
     float *w0s_u = lds;
     float *w0n_u = w0s_u + FU * HH1;
     float *w0s_i = w0n_u + FI * HH1;
     float *w0n_i = w0s_i + FI * HH1;
-    float *w1s_u = w0n_i + FU * HH1;
-    float *w1n_u = w1s_u + H1 * HH2;
-    float *w1s_i = w1n_u + H1 * HH2;
-    float *w1n_i = w1s_i + H1 * HH2;
-    float *bias = w1n_i + H1 * HH2;          // b0_u[H1] b0_i[H1] b1_u[H2] b1_i[H2]
-    float *wave0 = bias + 2 * H1 + 2 * H2;
+    float *w1s = w0n_i + FU * HH1;
+    float *w1n = w1s + H1 * HH2;
+    float *bias = w1n + H1 * HH2;            // b0_u[H1] b0_i[H1] b1[H2]
+    float *wave0 = bias + 2 * H1 + H2;
     stage_weight(w0s_u, a.w0_self[0], FU, HH1);
     stage_weight(w0n_u, a.w0_neigh[0], FI, HH1);
     stage_weight(w0s_i, a.w0_self[1], FI, HH1);
     stage_weight(w0n_i, a.w0_neigh[1], FU, HH1);
-    stage_weight(w1s_u, a.w1_self[0], H1, HH2);
-    stage_weight(w1n_u, a.w1_neigh[0], H1, HH2);
-    stage_weight(w1s_i, a.w1_self[1], H1, HH2);
-    stage_weight(w1n_i, a.w1_neigh[1], H1, HH2);
-    for (int i = threadIdx.x; i < 2 * H1 + 2 * H2; i += blockDim.x) {
+    stage_weight(w1s, a.w1_self[side], H1, HH2);
+    stage_weight(w1n, a.w1_neigh[side], H1, HH2);
+    for (int i = threadIdx.x; i < 2 * H1 + H2; i += blockDim.x) {
         float v = 0.f;
         if (i < H1) { if (a.b0[0]) v = a.b0[0][i]; }
         else if (i < 2 * H1) { if (a.b0[1]) v = a.b0[1][i - H1]; }
-        else if (i < 2 * H1 + H2) { if (a.b1[0]) v = a.b1[0][i - 2 * H1]; }
-        else { if (a.b1[1]) v = a.b1[1][i - 2 * H1 - H2]; }
+        else { if (a.b1[side]) v = a.b1[side][i - 2 * H1]; }
         bias[i] = v;
     }
     __syncthreads();
@@ -389,45 +426,67 @@ void sage2_kernel(const Sage2Args a) {
     float *A = wave0 + (size_t)wave * per_wave;
     float *H1t = A + 16 * LDA;
     int32_t *s_ids = reinterpret_cast<int32_t *>(H1t + a.h1_rows * LDH);
-    const long long n_walks = 2 * a.n_pairs;
     const int n_waves = blockDim.x >> 6;
-    for (long long w = (long long)blockIdx.x * n_waves + wave; w < n_walks; w += (long long)gridDim.x * n_waves) {
-        if (w < a.n_pairs)
-            walk_body<FU, FI, HH1, HH2, LDA, LDH>(a, w, 0, lane, A, H1t, s_ids, w0s_u, w0n_u, w0s_i, w0n_i, w1s_u, w1n_u,
-                                                  bias, bias + H1, bias + 2 * H1);
+    const long long my_blocks = (gridDim.x + 1 - side) >> 1;       // blocks serving this side
+    const long long stride = my_blocks * n_waves;
+    const long long base = side ? a.n_pairs : 0;
+    auto load_root = [&](long long p) -> int32_t {                 // -1 for ids outside the graph
+        const int32_t v = a.seeds[base + p];
+        return (unsigned long long)(long long)v < (unsigned long long)a.n_nodes ? v : -1;
+    };
+    long long p = (long long)(blockIdx.x >> 1) * n_waves + wave;
+    if (p >= a.n_pairs) return;
+    // the root of the next walk and its CSR row bounds are fetched one walk ahead
+    int32_t root = load_root(p);
+    int64_t ra = a.indptr[root >= 0 ? root : 0], rb = a.indptr[(root >= 0 ? root : 0) + 1];
+    for (; p < a.n_pairs; p += stride) {
+        const long long pn = p + stride;
+        const int32_t next_root = pn < a.n_pairs ? load_root(pn) : -1;
+        int64_t nra = 0, nrb = 0;
+        if (side == 0)
+            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF>(a, p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+                                                  w0s_u, w0n_u, w0s_i, w0n_i, w1s, w1n, bias, bias + H1, bias + 2 * H1);
         else
-            walk_body<FI, FU, HH1, HH2, LDA, LDH>(a, w, 1, lane, A, H1t, s_ids, w0s_i, w0n_i, w0s_u, w0n_u, w1s_i, w1n_i,
-                                                  bias + H1, bias, bias + 2 * H1 + H2);
+            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF>(a, a.n_pairs + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+                                                  w0s_i, w0n_i, w0s_u, w0n_u, w1s, w1n, bias + H1, bias, bias + 2 * H1);
+        root = next_root; ra = nra; rb = nrb;
     }
 }
 
-template <int FU, int FI, int HH1, int HH2>
-int launch(const Sage2Args &a, hipStream_t stream) {
+template <int FU, int FI, int HH1, int HH2, bool BUF>
+int launch_one(const Sage2Args &a, hipStream_t stream) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     int waves = kWaves;                                  // as many waves per CU as the LDS budget admits
     while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves) > kLdsMax) waves -= 2;
     const size_t lds = S::lds_bytes(a.n0, a.n1, waves);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
-    auto kern = sage2_kernel<FU, FI, HH1, HH2>;
+    auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF>;
     static thread_local const void *configured = nullptr;
     if (lds > 64 * 1024 && configured != (const void *)kern) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
         if (e != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage2_forward: cannot raise the LDS limit: %s", hipGetErrorString(e));
         configured = (const void *)kern;
     }
-    const long long n_walks = 2 * a.n_pairs;
-    long long blocks = (n_walks + waves - 1) / waves;
+    long long blocks = 2 * ((a.n_pairs + waves - 1) / waves);   // even blocks: user roots, odd: item roots
     if (blocks > 256) blocks = 256;                      // one block per CU, waves loop over walks
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, a);
     return gs::check_launch("gs_sage2_forward");
+}
+
+template <int FU, int FI, int HH1, int HH2>
+int launch(const Sage2Args &a, hipStream_t stream) {
+    // buffer addressing needs both tables inside a 4 GiB window
+    const long long lim = 0xFFFFFFF0LL;
+    if (a.n_rows[0] * FU * 4 < lim && a.n_rows[1] * FI * 4 < lim) return launch_one<FU, FI, HH1, HH2, true>(a, stream);
+    return launch_one<FU, FI, HH1, HH2, false>(a, stream);
 }
 
 // LDS of the smallest block this kernel runs with (4 waves)
 inline size_t sage2_lds(int Fu, int Fi, int H1, int H2, int n0, int n1) {
     const int fmax = Fu > Fi ? Fu : Fi, kmax = fmax > H1 ? fmax : H1;
     const int ids = ((n0 + n0 * n1) + 3) & ~3;
-    return (size_t)((Fu + Fi) * H1 + 2 * H1 * H2 + 2 * H1 + 2 * H2 +
-                    4 * (16 * (kmax + 4) + (1 + n0) * (H1 + 4) + ids)) * sizeof(float);
+    return (size_t)((Fu + Fi) * H1 + H1 * H2 + 2 * H1 + H2 +
+                    4 * (16 * (kmax + 4) + (1 + n0) * H1 + ids)) * sizeof(float);
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
