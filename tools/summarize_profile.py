@@ -15,7 +15,7 @@ from collections import defaultdict
 
 src, name = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ours = ('sage_fused_kernel', 'sample_kernel', 'gather_mean_kernel', 'gather_rows_kernel', 'rows_gemm_kernel',
+ours = ('sage2_kernel', 'sage_fused_kernel', 'sample_kernel', 'gather_mean_kernel', 'gather_rows_kernel', 'rows_gemm_kernel',
         'wgrad_kernel', 'wgrad_reduce_kernel', 'l2norm')
 
 
