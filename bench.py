@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batches', type=int, default=10)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL)')
+    ap.add_argument('--train-steps', type=int, default=20, help='steps of the secondary fwd+bwd+all-reduce+Adam timing (0: skip)')
     return ap.parse_args()
 
 
@@ -163,6 +164,43 @@ def main():
     err = engine.err_flag.tolist()
     assert err == [0, 0], "sampler reported %s" % err
 
+    # secondary: the training step (sample + forward + backward + gradient all-reduce + Adam)
+    train = None
+    if args.train_steps > 0:
+        from graphsage_amd.train import Trainer
+        try:
+            tr = Trainer(model, lr=1e-2, engine='plan', graph=graph, batch_size=b)
+        except Exception as ex:                              # shapes outside the static plan
+            tr = None
+            train = {"skipped": str(ex)[:200]}
+        if tr is not None:
+            tgt = (torch.arange(b, device=device) % 2).to(torch.float32)
+
+            def tstep(i):
+                k = my_batches[i % len(my_batches)]
+                return tr.step_device(seeds[k], tgt, walk_ids[k], rng_seed=gen.sampler.seed + 1)
+
+            for i in range(5):
+                tstep(i)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for i in range(args.train_steps):
+                tstep(5 + i)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t_el = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([t_el], dtype=torch.float64, device=sync_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t_el = float(tt.item())
+            assert tr.engine.err_flag.tolist() == [0, 0]
+            train = {"value": args.train_steps * b * world / t_el, "unit": "seed edges/s",
+                     "ms_per_step": t_el / args.train_steps * 1e3, "steps": args.train_steps,
+                     "what": "sample + fwd + bwd + flat-bucket all-reduce (RCCL for N>1) + Adam, MSE on concat->Dense(1,sigmoid)"}
+
     if rank == 0:
         total_edges = args.steps * b * world
         value = total_edges / elapsed
@@ -186,6 +224,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": engine.measured_traffic(),
                          "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes},
         }
+        if train is not None:
+            out["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, cfg, heads_u, heads_i, model, args.cpu_batches)
         print(json.dumps(out))

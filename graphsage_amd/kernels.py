@@ -163,7 +163,11 @@ def sage_project(x_self, x_mean, w_self, w_neigh, bias, act, out=None):
 
 
 def sage_project_bwd(x_self, x_mean, w_self, w_neigh, act, out, g_out, need_x_self=True, need_x_mean=True,
-                     need_bias=True):
+                     need_bias=True, g_w_self=None, g_w_neigh=None, g_bias=None, g_x_self=None, g_x_mean=None,
+                     workspace=None):
+    """Gradients of ``sage_project``.  Destination tensors may be passed in (views
+    of a flat gradient bucket, preallocated activations); missing ones are
+    allocated.  Returns (g_w_self, g_w_neigh, g_bias, g_x_self, g_x_mean)."""
     lib = load()
     m, fs, fn, h = _project_args(x_self, x_mean, w_self, w_neigh, None)
     _dev(g_out, torch.float32, 'g_out', 2)
@@ -174,17 +178,35 @@ def sage_project_bwd(x_self, x_mean, w_self, w_neigh, act, out, g_out, need_x_se
         if tuple(out.shape) != (m, h):
             raise ValueError("out must be (%d, %d)" % (m, h))
     dev = x_self.device
-    g_ws = torch.empty_like(w_self)
-    g_wn = torch.empty_like(w_neigh)
-    g_b = torch.empty(h, dtype=torch.float32, device=dev) if need_bias else None
-    g_xs = torch.empty_like(x_self) if need_x_self else None
-    g_xm = torch.empty_like(x_mean) if need_x_mean else None
+
+    def dest(t, shape, name, want=True):
+        if t is None:
+            return torch.empty(shape, dtype=torch.float32, device=dev) if want else None
+        _dev(t, torch.float32, name)
+        if t.numel() != int(torch.Size(shape).numel()):
+            raise ValueError("%s has %d elements, %s needed" % (name, t.numel(), tuple(shape)))
+        return t
+
+    g_ws = dest(g_w_self, w_self.shape, 'g_w_self')
+    g_wn = dest(g_w_neigh, w_neigh.shape, 'g_w_neigh')
+    g_b = dest(g_bias, (h,), 'g_bias', need_bias)
+    g_xs = dest(g_x_self, x_self.shape, 'g_x_self', need_x_self)
+    g_xm = dest(g_x_mean, x_mean.shape, 'g_x_mean', need_x_mean)
     ws_bytes = lib.gs_sage_project_bwd_workspace(fs, fn, h, m)
-    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dev)
+    if workspace is None:
+        workspace = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dev)
+    else:
+        _dev(workspace, torch.float32, 'workspace', 1)
+        if workspace.numel() * 4 < ws_bytes:
+            raise ValueError("workspace of %d bytes needed" % ws_bytes)
     check(lib.gs_sage_project_bwd(ptr(x_self), fs, ptr(x_mean), fn, m, ptr(w_self), ptr(w_neigh), h, ACT[act],
                                   ptr(out), ptr(g_out), ptr(g_ws), ptr(g_wn), ptr(g_b), ptr(g_xs), ptr(g_xm),
-                                  ptr(ws), ws.numel() * 4, stream_handle()), 'gs_sage_project_bwd')
+                                  ptr(workspace), workspace.numel() * 4, stream_handle()), 'gs_sage_project_bwd')
     return g_ws, g_wn, g_b, g_xs, g_xm
+
+
+def project_bwd_workspace_floats(fs, fn, h, m):
+    return max(load().gs_sage_project_bwd_workspace(int(fs), int(fn), int(h), int(m)) // 4, 1)
 
 
 def l2_normalize(x, out=None):

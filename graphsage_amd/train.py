@@ -106,7 +106,10 @@ class Trainer:
     """One optimisation step = batch -> embeddings -> head -> MSE -> backward ->
     gradient all-reduce -> Adam."""
 
-    def __init__(self, model, head=None, lr=1e-2, group=None):
+    def __init__(self, model, head=None, lr=1e-2, group=None, engine='auto', graph=None, batch_size=None):
+        """engine: 'autograd' runs the model through torch.autograd Functions (any
+        shape); 'plan' uses the static launch plan of ``SageTrainEngine`` (needs
+        ``graph`` and ``batch_size``); 'auto' picks the plan when it applies."""
         self.model = model.build()
         dev = self.model.parameters()[0].device
         emb_dim = self.model.dims[-1]['user']
@@ -115,6 +118,16 @@ class Trainer:
         self.bucket = FlatGradBucket(self.params)
         self.opt = Adam(self.params, self.bucket.flat, lr=lr)
         self.group = group
+        self.engine = None
+        if engine in ('auto', 'plan') and graph is not None and batch_size is not None:
+            from .train_engine import SageTrainEngine
+            try:
+                self.engine = SageTrainEngine(graph, self.model, batch_size)
+            except Exception:
+                if engine == 'plan':
+                    raise
+        elif engine == 'plan':
+            raise ValueError("engine='plan' needs graph and batch_size")
         self.broadcast_parameters()
 
     def broadcast_parameters(self):
@@ -133,6 +146,23 @@ class Trainer:
         pred = self.head(self.model(batch))
         y = torch.as_tensor(targets, dtype=torch.float32, device=pred.device).reshape(pred.shape)
         return ((pred - y) ** 2).mean(), pred
+
+    def step_device(self, seeds, targets, walk_ids=None, rng_seed=0):
+        """Training step on device-resident inputs through the static plan:
+        ``seeds`` int32[2B] roots (sources then destinations), ``targets``
+        float32[B] on the GPU."""
+        eng = self.engine
+        self.bucket.zero()
+        emb_u, emb_i = eng.forward_train(seeds, walk_ids, rng_seed)
+        emb_u = emb_u.detach().requires_grad_(True)
+        emb_i = emb_i.detach().requires_grad_(True)
+        pred = self.head([emb_u, emb_i])
+        loss = ((pred - targets.reshape(pred.shape)) ** 2).mean()
+        loss.backward()                                   # head gradients + embedding gradients
+        eng.backward(emb_u.grad, emb_i.grad)
+        self.bucket.all_reduce_mean(self.group)
+        self.opt.step()
+        return loss.detach(), pred.detach()
 
     def step(self, batch, targets):
         self.bucket.zero()

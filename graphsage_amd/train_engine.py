@@ -1,0 +1,139 @@
+"""Static launch plan for one training step of the GraphSAGE stack.
+
+Forward: the sampler kernel, then one fused kernel per (layer, node type) that
+also saves what the backward pass needs (layer 0: the gathered own rows and
+neighbor means, so nothing is gathered twice; layers >= 1: the neighbor means).
+Backward: per (layer, node type) the MFMA weight-gradient kernel with its
+ordered slab reduction, the input-gradient GEMM for layers >= 1, and the
+broadcast that undoes the dense neighbor mean.  Weight gradients are written
+straight into the views of the flat all-reduce bucket.  Feature tables are
+inputs of the reference model, not variables (``models.py:241``), so nothing is
+scattered back into them.
+"""
+import torch
+
+from . import kernels
+from .engine import SageForwardEngine, _TYPES
+
+
+class SageTrainEngine(SageForwardEngine):
+    def __init__(self, graph, model, batch_size):
+        super().__init__(graph, model, batch_size, use_fused=True, walk_kernel=False)
+        if not all(self.fused_layers):
+            raise kernels._lib.GsageError(
+                "the training plan needs the fused layer kernel (feature and hidden widths in {32, 64, 128}, "
+                "half-widths 16 or 32); use graphsage_amd.train.Trainer(engine='autograd') for other shapes")
+        m = self.model
+        dev = self.indptr.device
+        new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=dev)
+        self.z = {t: new(self.batch, m.dims[-1][t]) for t in _TYPES}          # last layer before l2norm
+        self.g_h = [{t: torch.zeros_like(self.h[layer][t]) for t in _TYPES} for layer in range(self.n_hops)]
+        self.g_xs = [None] + [{t: new(self.h[layer][t].shape[0], m.dims[layer][t]) for t in _TYPES}
+                              for layer in range(1, self.n_hops)]
+        self.g_xm = [None] + [{t: new(self.h[layer][t].shape[0], m.dims[layer][self.other[t]]) for t in _TYPES}
+                              for layer in range(1, self.n_hops)]
+        self.ws = [{t: torch.empty(kernels.project_bwd_workspace_floats(
+            m.dims[layer][t], m.dims[layer][self.other[t]], m.dims[layer + 1][t], self.h[layer][t].shape[0]),
+            dtype=torch.float32, device=dev) for t in _TYPES} for layer in range(self.n_hops)]
+        self._train_calls = {}
+
+    # ---- forward ------------------------------------------------------------------
+    def _train_call(self, layer, t):
+        key = (layer, t)
+        if key in self._train_calls:
+            return self._train_calls[key]
+        m, other = self.model, self.other
+        agg = m._aggs[layer][t]
+        last = layer == self.n_hops - 1
+        rows = self.h[layer][t].shape[0]
+        segs = []
+        for (s, h, side, r0, n) in self.segments[t]:
+            if h > self.n_hops - 1 - layer:
+                continue
+            if layer == 0:
+                segs.append({'head_ids': self._slot_ids(self.seeds_buf, h, side),
+                             'child_ids': self._slot_ids(self.seeds_buf, h + 1, side),
+                             'n_heads': n, 'n_child': self.fanouts[h]})
+            else:
+                _, c0, _cn = self.where[s + 2]
+                segs.append({'n_heads': n, 'n_child': self.fanouts[h], 'self_row0': r0, 'child_row0': c0})
+        if layer == 0:
+            (f_self, o_self), (f_neigh, o_neigh) = self.tables[t], self.tables[other[t]]
+            save_self = self.x_self[t]
+        else:
+            f_self, o_self, f_neigh, o_neigh = self.h[layer - 1][t], 0, self.h[layer - 1][other[t]], 0
+            save_self = None                                   # the own rows are h[layer-1] itself
+        out = self.z[t] if last else self.h[layer][t]
+        call = kernels.FusedLayerCall(f_self, o_self, f_neigh, o_neigh, segs, agg.w_self, agg.w_neigh, agg.bias,
+                                      agg.activation, False, out, save_self=save_self,
+                                      save_mean=self.x_mean[layer][t][:rows])
+        self._train_calls[key] = call
+        return call
+
+    def forward_train(self, seeds, walk_ids=None, rng_seed=0, replay=None):
+        """Returns the (user, item) embeddings; every intermediate the backward
+        pass needs stays in the engine's buffers."""
+        self.sample(seeds, walk_ids, rng_seed, replay)
+        for layer in range(self.n_hops):
+            for t in _TYPES:
+                call = self._train_call(layer, t)
+                if layer == 0:
+                    for i, (_, h, side, _, _) in enumerate(self.segments[t]):
+                        if h == 0:
+                            call.set_head_ids(i, self._slot_ids(seeds, 0, side))
+                call.run()
+        for t in _TYPES:
+            if self.model.normalize == "l2":
+                kernels.l2_normalize(self.z[t], out=self.emb[t])
+            else:
+                self.emb[t].copy_(self.z[t])
+        return self.emb['user'], self.emb['item']
+
+    # ---- backward -----------------------------------------------------------------
+    def backward(self, g_user, g_item):
+        """Gradients of every aggregator weight from the embedding gradients; they
+        are written into ``param.grad`` (which must exist, e.g. as views of a
+        flat bucket) and overwrite what was there."""
+        m, other, L = self.model, self.other, self.n_hops
+        g_emb = {'user': g_user.contiguous(), 'item': g_item.contiguous()}
+        g_out = {}
+        for t in _TYPES:
+            g_out[t] = kernels.l2_normalize_bwd(self.z[t], g_emb[t]) if m.normalize == "l2" else g_emb[t]
+        for layer in range(L - 1, -1, -1):
+            g_prev = self.g_h[layer - 1] if layer > 0 else None
+            for t in _TYPES:
+                agg = m._aggs[layer][t]
+                rows = self.h[layer][t].shape[0]
+                out = self.z[t] if layer == L - 1 else self.h[layer][t]
+                x_self = self.x_self[t] if layer == 0 else self.h[layer - 1][t][:rows]
+                for p in agg.parameters():
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                kernels.sage_project_bwd(
+                    x_self, self.x_mean[layer][t][:rows], agg.w_self, agg.w_neigh, agg.activation, out, g_out[t],
+                    need_x_self=layer > 0, need_x_mean=layer > 0, need_bias=agg.bias is not None,
+                    g_w_self=agg.w_self.grad, g_w_neigh=agg.w_neigh.grad,
+                    g_bias=None if agg.bias is None else agg.bias.grad,
+                    g_x_self=self.g_xs[layer][t] if layer > 0 else None,
+                    g_x_mean=self.g_xm[layer][t] if layer > 0 else None, workspace=self.ws[layer][t])
+            if layer == 0:
+                break
+            # gradient of h[layer-1]: head contribution (prefix rows) and neighbor contribution
+            # (every slot beyond the roots is the neighbor slot of the slot two below it)
+            for t in _TYPES:
+                for (s, h, side, r0, n) in self.segments[t]:
+                    if h > L - layer:                      # slot not alive at layer-1's output
+                        continue
+                    dst = g_prev[t][r0:r0 + n]
+                    wrote = False
+                    if h >= 1:                             # neighbor slot of slot s-2 (other type)
+                        _, p0, pn = self.where[s - 2]
+                        kernels.gather_mean_bwd(self.g_xm[layer][other[t]][p0:p0 + pn], None, self.fanouts[h - 1], dst)
+                        wrote = True
+                    if h <= L - 1 - layer:                 # head slot at this layer
+                        src = self.g_xs[layer][t][r0:r0 + n]
+                        if wrote:
+                            dst.add_(src)
+                        else:
+                            dst.copy_(src)
+            g_out = {t: g_prev[t] for t in _TYPES}
