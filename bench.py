@@ -178,7 +178,7 @@ def main():
 
             def tstep(i):
                 k = my_batches[i % len(my_batches)]
-                return tr.step_device(seeds[k], tgt, walk_ids[k], rng_seed=gen.sampler.seed + 1)
+                return tr.step_graph(seeds[k], tgt, walk_ids[k], rng_seed=gen.sampler.seed + 1)
 
             for i in range(5):
                 tstep(i)
@@ -199,7 +199,8 @@ def main():
             assert tr.engine.err_flag.tolist() == [0, 0]
             train = {"value": args.train_steps * b * world / t_el, "unit": "seed edges/s",
                      "ms_per_step": t_el / args.train_steps * 1e3, "steps": args.train_steps,
-                     "what": "sample + fwd + bwd + flat-bucket all-reduce (RCCL for N>1) + Adam, MSE on concat->Dense(1,sigmoid)"}
+                     "what": "sample + fwd + bwd + flat-bucket all-reduce (RCCL for N>1) + Adam, MSE on concat->Dense(1,sigmoid); "
+                             "launches replayed from a captured HIP graph"}
 
     if rank == 0:
         total_edges = args.steps * b * world

@@ -167,10 +167,10 @@ struct WgradSide {
     int nkb, ncb;        // 64-row blocks over K+1, 64-column blocks over N
 };
 
-constexpr int WG_ROWS = 32;            // rows of M staged per step
+constexpr int WG_ROWS = 64;            // rows of M staged per step
 
 __global__ __launch_bounds__(kThreads)
-void wgrad_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk) {
+void wgrad_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk, int vec0, int vec1) {
     __shared__ float Xs[WG_ROWS * W_LD];
     __shared__ float Gs[WG_ROWS * W_LD];
     const int tiles0 = s0.nkb * s0.ncb;
@@ -182,6 +182,7 @@ void wgrad_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk)
     float *__restrict__ slab_base = GS_SEL(slab);
     const int K = GS_SEL(K), N = GS_SEL(N), ldg = GS_SEL(ldg), ncb = GS_SEL(ncb);
 #undef GS_SEL
+    const bool vec = second ? vec1 : vec0;         // 16-byte loads of X, G and mask rows are legal
     const int tile = (int)blockIdx.y - (second ? tiles0 : 0);
     const int kb0 = (tile / ncb) * 64;            // first row of dW (k index) of this block
     const int col0 = (tile % ncb) * 64;
@@ -192,34 +193,53 @@ void wgrad_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk)
     const int wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, q = lane >> 4;
     const int nt = (min(64, N - col0) + 15) >> 4;
+    const bool bias_block = kb0 == 0;             // this block also forms the column sums (bias gradient)
 
     f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
 
     for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_ROWS) {
-        // 32 rows x 64 columns of X (column K is the constant 1 that yields the bias row)
-        // and of the masked gradient; 16 lanes cover one row
+        // 64 rows x 64 columns of X and of the masked gradient; 16 lanes cover one row
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < WG_ROWS / 16; ++pass) {
             const int row = pass * 16 + (tid >> 4);
             const int c4 = (tid & 15) * 4;
             const int64_t m = m0 + row;
             const bool live = m < m_end;
+            const int k = kb0 + c4, c = col0 + c4;
+            float xv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                if (vec && k + 3 < K) {
+                    const float4 t = *reinterpret_cast<const float4 *>(X + m * K + k);
+                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = kb0 + c4 + i;
-                float xv = 0.f;
-                if (live) xv = k < K ? X[m * K + k] : (k == K ? 1.f : 0.f);
-                Xs[row * W_LD + c4 + i] = xv;
-                const int c = col0 + c4 + i;
-                float gv = 0.f;
-                if (live && c < N) {
-                    gv = G[m * ldg + c];
-                    if (Mk && !(Mk[m * ldg + c] > 0.f)) gv = 0.f;
+                    for (int i = 0; i < 4; ++i) if (k + i < K) xv[i] = X[m * K + k + i];
                 }
-                Gs[row * W_LD + c4 + i] = gv;
+                if (vec && c + 3 < N) {
+                    const float4 t = *reinterpret_cast<const float4 *>(G + m * ldg + c);
+                    gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+                    if (Mk) {
+                        const float4 mk = *reinterpret_cast<const float4 *>(Mk + m * ldg + c);
+                        if (!(mk.x > 0.f)) gv[0] = 0.f;
+                        if (!(mk.y > 0.f)) gv[1] = 0.f;
+                        if (!(mk.z > 0.f)) gv[2] = 0.f;
+                        if (!(mk.w > 0.f)) gv[3] = 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (c + i < N) {
+                            gv[i] = G[m * ldg + c + i];
+                            if (Mk && !(Mk[m * ldg + c + i] > 0.f)) gv[i] = 0.f;
+                        }
+                    }
+                }
             }
+            *reinterpret_cast<float4 *>(Xs + row * W_LD + c4) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            *reinterpret_cast<float4 *>(Gs + row * W_LD + c4) = make_float4(gv[0], gv[1], gv[2], gv[3]);
         }
         __syncthreads();
 #pragma unroll
@@ -233,6 +253,10 @@ void wgrad_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk)
                 }
             }
         }
+        if (bias_block && wave == 0) {             // lane = column: sum the staged rows in row order
+#pragma unroll 8
+            for (int row = 0; row < WG_ROWS; ++row) bsum += Gs[row * W_LD + lane];
+        }
         __syncthreads();
     }
 
@@ -244,19 +268,29 @@ void wgrad_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = kb0 + wave * 16 + q * 4 + i;
-                if (k <= K && col < N) slab[(int64_t)k * N + col] = acc[ct][i];
+                if (k < K && col < N) slab[(int64_t)k * N + col] = acc[ct][i];
             }
         }
     }
+    if (bias_block && wave == 0 && col0 + lane < N) slab[(int64_t)K * N + col0 + lane] = bsum;
 }
 
+// Adds the per-chunk slabs: element e is summed by four threads that take chunks c = j, j+4, ...
+// each in increasing order, and their partial sums are added in a fixed order: reproducible.
 __global__ __launch_bounds__(kThreads)
 void wgrad_reduce_kernel(const float *__restrict__ slab, int n_chunks, int K, int N,
                          float *__restrict__ gW, float *__restrict__ gbias) {
+    __shared__ float part[kThreads];
     const int total = (K + 1) * N;
-    for (int e = blockIdx.x * kThreads + threadIdx.x; e < total; e += gridDim.x * kThreads) {
-        float s = 0.f;
-        for (int c = 0; c < n_chunks; ++c) s += slab[(int64_t)c * total + e];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = threadIdx.x >> 6;
+    float s = 0.f;
+    if (e < total)
+        for (int c = j; c < n_chunks; c += 4) s += slab[(int64_t)c * total + e];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (j == 0 && e < total) {
+        s = ((part[threadIdx.x] + part[threadIdx.x + 64]) + part[threadIdx.x + 128]) + part[threadIdx.x + 192];
         if (e < K * N) { if (gW) gW[e] = s; }
         else if (gbias) gbias[e - K * N] = s;
     }
@@ -380,20 +414,22 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
         if (M > 0) {
             WgradSide a{}, b{};
             a.X = x_self; a.G = g_out; a.mask = mask; a.slab = slab0; a.K = Fs; a.N = Hh; a.ldg = H;
-            a.nkb = (Fs + 1 + 63) / 64; a.ncb = (Hh + 63) / 64;
+            a.nkb = (Fs + 63) / 64; a.ncb = (Hh + 63) / 64;
             b.X = x_mean; b.G = g_out + Hh; b.mask = mask ? mask + Hh : nullptr; b.slab = slab1; b.K = Fn; b.N = Hh; b.ldg = H;
-            b.nkb = (Fn + 1 + 63) / 64; b.ncb = a.ncb;
+            b.nkb = (Fn + 63) / 64; b.ncb = a.ncb;
             const int by = a.nkb * a.ncb + b.nkb * b.ncb;
             if (by > 65535) return gs::fail(GS_ELIMIT, "gs_sage_project_bwd: %d weight tiles exceed the grid limit", by);
-            hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nc, (unsigned)by), dim3(kThreads), 0, s, a, b, M, rpc);
+            const bool g_ok = H % 4 == 0 && Hh % 4 == 0 && aligned16(g_out) && (!mask || aligned16(mask));
+            const int v0 = g_ok && Fs % 4 == 0 && aligned16(x_self), v1 = g_ok && Fn % 4 == 0 && aligned16(x_mean);
+            hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)nc, (unsigned)by), dim3(kThreads), 0, s, a, b, M, rpc, v0, v1);
             if (int rc = gs::check_launch("gs_sage_project_bwd (wgrad)")) return rc;
         }
         // bias gradient: row Fs of the self slab holds columns 0..Hh-1, row Fn of the neighbor slab Hh..H-1
         const int tot0 = (Fs + 1) * Hh, tot1 = (Fn + 1) * Hh;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot0 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot0 + 63) / 64)), dim3(kThreads), 0, s,
                            slab0, (int)nc, Fs, Hh, g_W_self, g_bias);
         if (int rc = gs::check_launch("gs_sage_project_bwd (reduce self)")) return rc;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot1 + 63) / 64)), dim3(kThreads), 0, s,
                            slab1, (int)nc, Fn, Hh, g_W_neigh, g_bias ? g_bias + Hh : nullptr);
         if (int rc = gs::check_launch("gs_sage_project_bwd (reduce neigh)")) return rc;
     }

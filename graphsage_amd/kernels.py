@@ -219,13 +219,18 @@ def l2_normalize(x, out=None):
     return out
 
 
-def l2_normalize_bwd(x, g_out):
+def l2_normalize_bwd(x, g_out, g_x=None):
     lib = load()
     _dev(x, torch.float32, 'x', 2)
     _dev(g_out, torch.float32, 'g_out', 2)
     if g_out.shape != x.shape:
         raise ValueError("shapes differ")
-    g_x = torch.empty_like(x)
+    if g_x is None:
+        g_x = torch.empty_like(x)
+    else:
+        _dev(g_x, torch.float32, 'g_x', 2)
+        if g_x.shape != x.shape:
+            raise ValueError("shapes differ")
     check(lib.gs_l2_normalize_bwd(ptr(x), ptr(g_out), x.shape[0], x.shape[1], ptr(g_x), stream_handle()),
           'gs_l2_normalize_bwd')
     return g_x
@@ -396,3 +401,68 @@ class Sage2Call:
                                          ptr(walk_ids), ptr(replay), *self._fixed_b, ptr(err_flag), stream_handle()),
               'gs_sage2_forward')
         return self.emb
+
+
+def link_head(emb_user, emb_item, kernel, bias, pred=None):
+    """pred = sigmoid(concat(u, i) @ kernel + bias), shape (B,)."""
+    lib = load()
+    _dev(emb_user, torch.float32, 'emb_user', 2)
+    _dev(emb_item, torch.float32, 'emb_item', 2)
+    b, e = emb_user.shape
+    if tuple(emb_item.shape) != (b, e) or kernel.numel() != 2 * e or bias.numel() != 1:
+        raise ValueError("head shapes do not match")
+    _dev(kernel, torch.float32, 'kernel')
+    _dev(bias, torch.float32, 'bias')
+    if pred is None:
+        pred = torch.empty(b, dtype=torch.float32, device=emb_user.device)
+    check(lib.gs_link_head_fwd(ptr(emb_user), ptr(emb_item), b, e, ptr(kernel), ptr(bias), ptr(pred),
+                               stream_handle()), 'gs_link_head_fwd')
+    return pred
+
+
+class LinkHeadStep:
+    """Prepared ``gs_link_head_mse_fwd_bwd``: prediction, MSE loss and all head
+    gradients in one pass over preallocated buffers."""
+
+    def __init__(self, batch, emb_dim, kernel, bias, g_kernel, g_bias, device):
+        lib = load()
+        for name, t, n in (('kernel', kernel, 2 * emb_dim), ('bias', bias, 1), ('g_kernel', g_kernel, 2 * emb_dim),
+                           ('g_bias', g_bias, 1)):
+            _dev(t, torch.float32, name)
+            if t.numel() != n:
+                raise ValueError("%s must have %d elements" % (name, n))
+        self.b, self.e = int(batch), int(emb_dim)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        self.pred, self.loss = new(self.b), new(1)
+        self.g_user, self.g_item = new(self.b, self.e), new(self.b, self.e)
+        self.ws = new(max(lib.gs_link_head_workspace(self.b, self.e) // 4, 1))
+        self._lib = lib
+        self._keep = (kernel, bias, g_kernel, g_bias)
+
+    def run(self, emb_user, emb_item, targets):
+        kernel, bias, g_kernel, g_bias = self._keep
+        for name, t, shape in (('emb_user', emb_user, (self.b, self.e)), ('emb_item', emb_item, (self.b, self.e))):
+            _dev(t, torch.float32, name, 2)
+            if tuple(t.shape) != shape:
+                raise ValueError("%s must be %s" % (name, shape))
+        _dev(targets, torch.float32, 'targets')
+        if targets.numel() != self.b:
+            raise ValueError("targets must have %d entries" % self.b)
+        check(self._lib.gs_link_head_mse_fwd_bwd(ptr(emb_user), ptr(emb_item), self.b, self.e, ptr(kernel), ptr(bias),
+                                                 ptr(targets), ptr(self.pred), ptr(self.loss), ptr(self.g_user),
+                                                 ptr(self.g_item), ptr(g_kernel), ptr(g_bias), ptr(self.ws),
+                                                 self.ws.numel() * 4, stream_handle()), 'gs_link_head_mse_fwd_bwd')
+        return self.loss, self.pred
+
+
+def adam_step(params_flat, grads_flat, m, v, lr_t, beta1, beta2, eps, lr_t_device=None):
+    """lr_t_device: optional 1-element GPU tensor holding the rate (read by the kernel)."""
+    lib = load()
+    if lr_t_device is not None:
+        _dev(lr_t_device, torch.float32, 'lr_t_device')
+    for name, t in (('params', params_flat), ('grads', grads_flat), ('m', m), ('v', v)):
+        _dev(t, torch.float32, name, 1)
+        if t.numel() != params_flat.numel():
+            raise ValueError("flat optimizer buffers differ in length")
+    check(lib.gs_adam_step(ptr(params_flat), ptr(grads_flat), ptr(m), ptr(v), params_flat.numel(), float(lr_t),
+                           ptr(lr_t_device), float(beta1), float(beta2), float(eps), stream_handle()), 'gs_adam_step')

@@ -10,8 +10,10 @@ average ALL gradients with a single RCCL all-reduce over one flat fp32 bucket
 (a few thousand to a few hundred thousand floats: latency-bound, so one
 collective per step is the right granularity on xGMI).
 
-The link head and the optimizer update are a handful of tiny dense ops and use
-torch tensor arithmetic on the GPU.
+On the GPU the link head with its loss and gradients (``gs_link_head_mse_fwd_bwd``)
+and the optimizer update (``gs_adam_step`` over flat parameter storage) are HIP
+kernels too; the torch formulations below them serve host tensors (tests under
+gloo) and the autograd path.
 """
 import math
 
@@ -56,10 +58,17 @@ class FlatGradBucket:
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        # parameters move into one flat buffer as well (their tensors become views of it), so the
+        # optimizer update is a single elementwise pass
+        self.flat_params = torch.empty(total, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            n = p.numel()
+            with torch.no_grad():
+                self.flat_params[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_params[off:off + n].view_as(p)
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
 
     def zero(self):
         self.flat.zero_()
@@ -81,20 +90,33 @@ class Adam:
     0.999, epsilon 1e-7, no amsgrad; ``lr_t = lr * sqrt(1-b2^t) / (1-b1^t)``,
     ``p -= lr_t * m / (sqrt(v) + eps)`` (the TF2 formulation)."""
 
-    def __init__(self, params, grads_flat, lr=1e-2, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    def __init__(self, params, grads_flat, lr=1e-2, beta_1=0.9, beta_2=0.999, epsilon=1e-7, params_flat=None):
         self.params = list(params)
         self.g = grads_flat
+        self.p_flat = params_flat
+        self.lr_dev = None
         self.lr, self.b1, self.b2, self.eps = lr, beta_1, beta_2, epsilon
         self.m = torch.zeros_like(grads_flat)
         self.v = torch.zeros_like(grads_flat)
         self.t = 0
 
     @torch.no_grad()
-    def step(self):
+    def step(self, launch=True):
+        """launch=False only refreshes the device-side rate (the update kernel
+        itself is then part of a replayed HIP graph)."""
         self.t += 1
+        lr_t = self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        if self.p_flat is not None and self.g.is_cuda:
+            from . import kernels
+            if self.lr_dev is not None:                  # graph replay: the rate travels through memory
+                self.lr_dev.fill_(lr_t)
+                if not launch:
+                    return
+            kernels.adam_step(self.p_flat, self.g, self.m, self.v, lr_t, self.b1, self.b2, self.eps,
+                              lr_t_device=self.lr_dev)
+            return
         self.m.mul_(self.b1).add_(self.g, alpha=1 - self.b1)
         self.v.mul_(self.b2).addcmul_(self.g, self.g, value=1 - self.b2)
-        lr_t = self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
         upd = self.m / (self.v.sqrt() + self.eps)
         off = 0
         for p in self.params:
@@ -116,7 +138,8 @@ class Trainer:
         self.head = head or LinkHead(emb_dim, dev)
         self.params = self.model.parameters() + self.head.parameters()
         self.bucket = FlatGradBucket(self.params)
-        self.opt = Adam(self.params, self.bucket.flat, lr=lr)
+        self.opt = Adam(self.params, self.bucket.flat, lr=lr, params_flat=self.bucket.flat_params)
+        self._head_step = None
         self.group = group
         self.engine = None
         if engine in ('auto', 'plan') and graph is not None and batch_size is not None:
@@ -151,18 +174,78 @@ class Trainer:
         """Training step on device-resident inputs through the static plan:
         ``seeds`` int32[2B] roots (sources then destinations), ``targets``
         float32[B] on the GPU."""
+        from . import kernels
         eng = self.engine
-        self.bucket.zero()
+        if self._head_step is None:
+            self._head_step = kernels.LinkHeadStep(eng.batch, self.head.kernel.shape[0] // 2, self.head.kernel,
+                                                   self.head.bias, self.head.kernel.grad, self.head.bias.grad,
+                                                   self.head.kernel.device)
+        # every gradient of the bucket is overwritten by this step's kernels: no zeroing pass
         emb_u, emb_i = eng.forward_train(seeds, walk_ids, rng_seed)
-        emb_u = emb_u.detach().requires_grad_(True)
-        emb_i = emb_i.detach().requires_grad_(True)
-        pred = self.head([emb_u, emb_i])
-        loss = ((pred - targets.reshape(pred.shape)) ** 2).mean()
-        loss.backward()                                   # head gradients + embedding gradients
-        eng.backward(emb_u.grad, emb_i.grad)
+        loss, pred = self._head_step.run(emb_u, emb_i, targets)
+        eng.backward(self._head_step.g_user, self._head_step.g_item)
         self.bucket.all_reduce_mean(self.group)
         self.opt.step()
-        return loss.detach(), pred.detach()
+        return loss, pred.reshape(-1, 1)
+
+    # -- HIP-graph replay of the step ---------------------------------------------------
+    def _graph_body(self, with_update):
+        from . import kernels
+        eng = self.engine
+        emb_u, emb_i = eng.forward_train(eng.seeds_buf, self._walk_buf, self._graph_seed)
+        self._head_step.run(emb_u, emb_i, self._target_buf)
+        eng.backward(self._head_step.g_user, self._head_step.g_item)
+        if with_update:
+            kernels.adam_step(self.opt.p_flat, self.opt.g, self.opt.m, self.opt.v, 0.0, self.opt.b1, self.opt.b2,
+                              self.opt.eps, lr_t_device=self.opt.lr_dev)
+
+    def step_graph(self, seeds, targets, walk_ids, rng_seed=0):
+        """``step_device`` as a captured HIP graph: the ~30 launches of a step are
+        replayed by one call, which removes the per-launch host cost.  Inputs are
+        copied into static buffers; the sampling key is fixed at capture (draws
+        still differ per link through ``walk_ids``), so a new ``rng_seed`` - a new
+        epoch - recaptures.  With more than one rank the all-reduce stays outside
+        the graph, between the gradient graph and the update kernel."""
+        import torch.distributed as dist
+        from . import kernels
+        eng = self.engine
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if self._head_step is None:
+            self._head_step = kernels.LinkHeadStep(eng.batch, self.head.kernel.shape[0] // 2, self.head.kernel,
+                                                   self.head.bias, self.head.kernel.grad, self.head.bias.grad,
+                                                   self.head.kernel.device)
+        if getattr(self, '_graph', None) is None or self._graph_seed != rng_seed:
+            dev = eng.seeds_buf.device
+            self._walk_buf = torch.zeros(2 * eng.batch, dtype=torch.int64, device=dev)
+            self._target_buf = torch.zeros(eng.batch, dtype=torch.float32, device=dev)
+            self.opt.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._graph_seed = rng_seed
+            eng.seeds_buf.copy_(seeds)
+            self._walk_buf.copy_(walk_ids)
+            self._target_buf.copy_(targets)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                # warm-up outside capture (lazy plan construction)
+                self.opt.lr_dev.zero_()                  # rate 0: the warm-up must not move the weights
+                m_save, v_save = self.opt.m.clone(), self.opt.v.clone()
+                self._graph_body(not multi)
+                self.opt.m.copy_(m_save)
+                self.opt.v.copy_(v_save)
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._graph_body(not multi)
+        eng.seeds_buf.copy_(seeds)
+        self._walk_buf.copy_(walk_ids)
+        self._target_buf.copy_(targets)
+        if multi:
+            self._graph.replay()
+            self.bucket.all_reduce_mean(self.group)
+            self.opt.step()
+        else:
+            self.opt.step(launch=False)                  # sets the device-side rate for this step
+            self._graph.replay()
+        return self._head_step.loss, self._head_step.pred.reshape(-1, 1)
 
     def step(self, batch, targets):
         self.bucket.zero()

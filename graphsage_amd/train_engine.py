@@ -27,6 +27,7 @@ class SageTrainEngine(SageForwardEngine):
         dev = self.indptr.device
         new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=dev)
         self.z = {t: new(self.batch, m.dims[-1][t]) for t in _TYPES}          # last layer before l2norm
+        self.g_z = {t: new(self.batch, m.dims[-1][t]) for t in _TYPES}
         self.g_h = [{t: torch.zeros_like(self.h[layer][t]) for t in _TYPES} for layer in range(self.n_hops)]
         self.g_xs = [None] + [{t: new(self.h[layer][t].shape[0], m.dims[layer][t]) for t in _TYPES}
                               for layer in range(1, self.n_hops)]
@@ -77,7 +78,7 @@ class SageTrainEngine(SageForwardEngine):
         for layer in range(self.n_hops):
             for t in _TYPES:
                 call = self._train_call(layer, t)
-                if layer == 0:
+                if layer == 0 and seeds.data_ptr() != self.seeds_buf.data_ptr():
                     for i, (_, h, side, _, _) in enumerate(self.segments[t]):
                         if h == 0:
                             call.set_head_ids(i, self._slot_ids(seeds, 0, side))
@@ -98,7 +99,8 @@ class SageTrainEngine(SageForwardEngine):
         g_emb = {'user': g_user.contiguous(), 'item': g_item.contiguous()}
         g_out = {}
         for t in _TYPES:
-            g_out[t] = kernels.l2_normalize_bwd(self.z[t], g_emb[t]) if m.normalize == "l2" else g_emb[t]
+            g_out[t] = (kernels.l2_normalize_bwd(self.z[t], g_emb[t], g_x=self.g_z[t]) if m.normalize == "l2"
+                        else g_emb[t])
         for layer in range(L - 1, -1, -1):
             g_prev = self.g_h[layer - 1] if layer > 0 else None
             for t in _TYPES:

@@ -224,6 +224,38 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
                      float *emb, int32_t *out_hop1, int32_t *out_hop2,
                      int32_t *err_flag, void *stream);
 
+/*
+ * Link head of the reference's training script: concat(user_emb, item_emb) ->
+ * Dense(1, sigmoid) (link_utils.py:167-168,244-247 as used at
+ * train_movielens.py:179), kernel device float[2E], bias device float[1].
+ *   pred[b] = sigmoid(<concat(u[b], i[b]), kernel> + bias)          device float[B]
+ * gs_link_head_mse_fwd_bwd additionally evaluates the mean-squared-error loss
+ * of train_movielens.py:186 against targets[B] (loss: device float[1]) and all
+ * its gradients in the same pass: g_emb_user / g_emb_item [B, E], g_kernel [2E],
+ * g_bias [1] (overwritten).  workspace: device scratch of at least
+ * gs_link_head_workspace(B, E) bytes (per-block partial sums, added in block
+ * order).  E <= 256.
+ */
+size_t gs_link_head_workspace(int64_t B, int E);
+int gs_link_head_fwd(const float *emb_user, const float *emb_item, int64_t B, int E,
+                     const float *kernel, const float *bias, float *pred, void *stream);
+int gs_link_head_mse_fwd_bwd(const float *emb_user, const float *emb_item, int64_t B, int E,
+                             const float *kernel, const float *bias, const float *targets,
+                             float *pred, float *loss, float *g_emb_user, float *g_emb_item,
+                             float *g_kernel, float *g_bias,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Adam update on flat storage, the optimizer of train_movielens.py:185 in the
+ * TF2/Keras formulation: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr_t * m / (sqrt(v) + eps), with the caller passing the bias-corrected
+ * rate lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) -- by value, or, when
+ * lr_t_device != NULL, as a device float read at run time (so a captured HIP
+ * graph of the step can be replayed while the rate changes).
+ */
+int gs_adam_step(float *params, const float *grads, float *m, float *v, int64_t n,
+                 float lr_t, const float *lr_t_device, float beta1, float beta2, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,3 +136,66 @@ def test_plan_engine_step_equals_autograd_step(cuda, ns, sizes, f):
     assert float((g0 - g1).abs().max()) <= 2e-5 * scale
     for a, c in zip(p0, p1):
         assert float((a - c).abs().max()) < 2e-4
+
+
+def test_link_head_kernel_and_adam_kernel(cuda):
+    from graphsage_amd import kernels
+    gen = torch.Generator().manual_seed(0)
+    for b, e in [(100, 32), (4096, 32), (7, 64), (33, 100)]:
+        u = torch.randn(b, e, generator=gen, dtype=torch.float64, requires_grad=True)
+        i = torch.randn(b, e, generator=gen, dtype=torch.float64, requires_grad=True)
+        k = (torch.randn(2 * e, 1, generator=gen, dtype=torch.float64) * 0.3).requires_grad_(True)
+        bias = torch.tensor([0.1], dtype=torch.float64, requires_grad=True)
+        y = (torch.rand(b, generator=gen) > 0.5).double()
+        pred = omodel.link_head(u, i, k, bias)
+        loss = omodel.mse_loss(pred, y)
+        loss.backward()
+        f = lambda t: t.detach().float().to(cuda).contiguous()
+        gk, gb = torch.zeros(2 * e, 1, device=cuda), torch.zeros(1, device=cuda)
+        step = kernels.LinkHeadStep(b, e, f(k), f(bias), gk, gb, cuda)
+        l, p = step.run(f(u), f(i), f(y))
+        assert abs(float(l) - float(loss)) < 1e-6
+        assert float((p.cpu().double() - pred.detach().reshape(-1)).abs().max()) < 1e-6
+        for got, want in ((step.g_user, u.grad), (step.g_item, i.grad), (gk, k.grad), (gb, bias.grad)):
+            sc = float(want.abs().max())
+            assert float((got.cpu().double().reshape(want.shape) - want).abs().max()) <= 1e-5 * sc
+        assert torch.equal(kernels.link_head(f(u), f(i), f(k), f(bias)), p)
+    # Adam kernel against the update rule
+    n = 1000
+    p0 = torch.randn(n, generator=gen)
+    g = torch.randn(n, generator=gen)
+    pf, m, v = p0.clone().to(cuda), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    x, mm, vv = p0.double().numpy().copy(), np.zeros(n), np.zeros(n)
+    for t in range(1, 4):
+        lr_t = 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        kernels.adam_step(pf, g.to(cuda), m, v, lr_t, 0.9, 0.999, 1e-7)
+        mm = 0.9 * mm + 0.1 * g.double().numpy()
+        vv = 0.999 * vv + 0.001 * g.double().numpy() ** 2
+        x = x - lr_t * mm / (np.sqrt(vv) + 1e-7)
+        np.testing.assert_allclose(pf.cpu().numpy(), x, rtol=2e-5, atol=1e-6)
+
+
+def test_graph_replayed_steps_equal_eager_steps(cuda):
+    g, links, targets = _toy(4, fu=64, fi=64)
+    b, ns, sizes = 32, [6, 3], [32, 32]
+    lk = np.asarray(links)
+    outs = []
+    for mode in ('eager', 'graph'):
+        gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+        model = ga.GraphSAGE(sizes, gen, seed=11).build()
+        from graphsage_amd.train import LinkHead
+        tr = Trainer(model, head=LinkHead(32, cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
+        losses = []
+        for k in range(5):
+            part = lk[k * b:(k + 1) * b]
+            seeds = torch.from_numpy(np.concatenate([part[:, 0], part[:, 1]]).astype(np.int32)).to(cuda)
+            wid = torch.arange(2 * b, dtype=torch.int64, device=cuda) + 1000 * k
+            t = torch.from_numpy(targets[k * b:(k + 1) * b]).to(cuda)
+            fn = tr.step_device if mode == 'eager' else tr.step_graph
+            loss, _ = fn(seeds, t, wid, rng_seed=9)
+            losses.append(float(loss))
+        outs.append((losses, [p.detach().clone() for p in tr.params]))
+    (l0, p0), (l1, p1) = outs
+    assert l0 == l1, (l0, l1)                                # same kernels, same order: same bits
+    for a, c in zip(p0, p1):
+        assert torch.equal(a, c)
