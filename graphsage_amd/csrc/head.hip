@@ -84,12 +84,23 @@ void link_head_kernel(const float *__restrict__ eu, const float *__restrict__ ei
     }
 }
 
+// 16 threads per output element take blocks b = j, j+16, ... in increasing order; their partial
+// sums are added in index order.
 __global__ __launch_bounds__(kThreads)
 void link_head_reduce_kernel(const float *__restrict__ slab, int n_blocks, int C, float inv_b,
                              float *__restrict__ g_kernel, float *__restrict__ g_bias, float *__restrict__ loss) {
-    for (int c = blockIdx.x * kThreads + threadIdx.x; c < C + 2; c += gridDim.x * kThreads) {
-        float s = 0.f;
-        for (int b = 0; b < n_blocks; ++b) s += slab[(size_t)b * (C + 2) + c];
+    __shared__ float part[kThreads];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int j = threadIdx.x >> 4;
+    float s = 0.f;
+    if (c < C + 2)
+        for (int b = j; b < n_blocks; b += 16) s += slab[(size_t)b * (C + 2) + c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (j == 0 && c < C + 2) {
+        s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += part[g * 16 + threadIdx.x];
         if (c < C) g_kernel[c] = s;
         else if (c == C) g_bias[0] = s;
         else loss[0] = s * inv_b;
@@ -152,7 +163,8 @@ extern "C" int gs_link_head_mse_fwd_bwd(const float *emb_user, const float *emb_
     hipLaunchKernelGGL(link_head_kernel<true>, dim3(blocks), dim3(kThreads), 0, s, emb_user, emb_item, B, E, kernel, bias,
                        targets, pred, g_emb_user, g_emb_item, static_cast<float *>(workspace));
     if (int rc = gs::check_launch("gs_link_head_mse_fwd_bwd")) return rc;
-    hipLaunchKernelGGL(link_head_reduce_kernel, dim3(1), dim3(kThreads), 0, s, static_cast<const float *>(workspace), blocks,
+    hipLaunchKernelGGL(link_head_reduce_kernel, dim3((unsigned)((2 * E + 2 + 15) / 16)), dim3(kThreads), 0, s,
+                       static_cast<const float *>(workspace), blocks,
                        2 * E, 1.f / (float)B, g_kernel, g_bias, loss);
     return gs::check_launch("gs_link_head_mse_fwd_bwd (reduce)");
 }

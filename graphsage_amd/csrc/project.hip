@@ -275,22 +275,35 @@ void wgrad_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk,
     if (bias_block && wave == 0 && col0 + lane < N) slab[(int64_t)K * N + col0 + lane] = bsum;
 }
 
-// Adds the per-chunk slabs: element e is summed by four threads that take chunks c = j, j+4, ...
-// each in increasing order, and their partial sums are added in a fixed order: reproducible.
+// Adds the per-chunk slabs of both halves in one launch (blockIdx.y = half).  Element e is summed
+// by sixteen threads that take chunks c = j, j+16, ... each in increasing order; their partial
+// sums are then added in index order: the result does not depend on scheduling.
+struct ReduceSide {
+    const float *slab;
+    float *gW, *gbias;
+    int K;
+};
+
 __global__ __launch_bounds__(kThreads)
-void wgrad_reduce_kernel(const float *__restrict__ slab, int n_chunks, int K, int N,
-                         float *__restrict__ gW, float *__restrict__ gbias) {
+void wgrad_reduce_kernel(ReduceSide s0, ReduceSide s1, int n_chunks, int N) {
     __shared__ float part[kThreads];
+    const bool second = blockIdx.y == 1;
+    const float *__restrict__ slab = second ? s1.slab : s0.slab;
+    float *__restrict__ gW = second ? s1.gW : s0.gW;
+    float *__restrict__ gbias = second ? s1.gbias : s0.gbias;
+    const int K = second ? s1.K : s0.K;
     const int total = (K + 1) * N;
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j = threadIdx.x >> 6;
+    const int e = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int j = threadIdx.x >> 4;
     float s = 0.f;
     if (e < total)
-        for (int c = j; c < n_chunks; c += 4) s += slab[(int64_t)c * total + e];
+        for (int c = j; c < n_chunks; c += 16) s += slab[(int64_t)c * total + e];
     part[threadIdx.x] = s;
     __syncthreads();
     if (j == 0 && e < total) {
-        s = ((part[threadIdx.x] + part[threadIdx.x + 64]) + part[threadIdx.x + 128]) + part[threadIdx.x + 192];
+        s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += part[g * 16 + threadIdx.x];
         if (e < K * N) { if (gW) gW[e] = s; }
         else if (gbias) gbias[e - K * N] = s;
     }
@@ -350,7 +363,7 @@ inline int check_project_shape(const char *who, int Fs, int Fn, int64_t M, int H
 
 // chunks of the M dimension for the weight-gradient partial sums
 inline void wgrad_chunks(int64_t M, int64_t *rows_per_chunk, int64_t *n_chunks) {
-    int64_t rpc = 512;
+    int64_t rpc = 128;                   // small chunks: enough blocks to fill the chip at M ~ 1e5
     while ((M + rpc - 1) / rpc > 1024) rpc *= 2;
     *rows_per_chunk = rpc;
     *n_chunks = M > 0 ? (M + rpc - 1) / rpc : 0;
@@ -425,13 +438,10 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
             if (int rc = gs::check_launch("gs_sage_project_bwd (wgrad)")) return rc;
         }
         // bias gradient: row Fs of the self slab holds columns 0..Hh-1, row Fn of the neighbor slab Hh..H-1
-        const int tot0 = (Fs + 1) * Hh, tot1 = (Fn + 1) * Hh;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot0 + 63) / 64)), dim3(kThreads), 0, s,
-                           slab0, (int)nc, Fs, Hh, g_W_self, g_bias);
-        if (int rc = gs::check_launch("gs_sage_project_bwd (reduce self)")) return rc;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot1 + 63) / 64)), dim3(kThreads), 0, s,
-                           slab1, (int)nc, Fn, Hh, g_W_neigh, g_bias ? g_bias + Hh : nullptr);
-        if (int rc = gs::check_launch("gs_sage_project_bwd (reduce neigh)")) return rc;
+        ReduceSide r0{slab0, g_W_self, g_bias, Fs}, r1{slab1, g_W_neigh, g_bias ? g_bias + Hh : nullptr, Fn};
+        const int tot = ((Fs > Fn ? Fs : Fn) + 1) * Hh;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 15) / 16), 2), dim3(kThreads), 0, s, r0, r1, (int)nc, Hh);
+        if (int rc = gs::check_launch("gs_sage_project_bwd (reduce)")) return rc;
     }
 
     if ((g_x_self || g_x_mean) && M > 0) {
