@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batches', type=int, default=10)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL)')
+    ap.add_argument('--train-timeout', type=int, default=300, help='seconds before the train timing is abandoned')
     ap.add_argument('--train-steps', type=int, default=20, help='steps of the secondary fwd+bwd+all-reduce+Adam timing (0: skip)')
     return ap.parse_args()
 
@@ -93,8 +94,42 @@ def cpu_baseline(graph, cfg, heads_u, heads_i, model, n_batches, batch=100):
             "host_cpus": os.cpu_count()}
 
 
+def result_line(args, cfg, engine, world, b, fwd, train, cpu):
+    """The one JSON line rank 0 prints."""
+    elapsed = fwd["elapsed"]
+    value = args.steps * b * world / elapsed
+    samp_bytes, agg_bytes = engine.algorithmic_bytes()
+    dom_ms = fwd["probes"]
+    dom_avg = sum(dom_ms) / max(len(dom_ms), 1) * 1e-3
+    dom_bytes = engine.dominant_bytes()
+    achieved = dom_bytes / dom_avg / 1e9 if dom_avg > 0 else 0.0
+    out = {
+        "metric": "seed edges/sec (2-hop sample+aggregate fwd)" if len(cfg['fan']) == 2
+                  else "seed edges/sec (%d-hop sample+aggregate fwd)" % len(cfg['fan']),
+        "value": value, "unit": "seed edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.workload, cfg['desc']), "batch_per_gpu": b,
+                   "layer_sizes": cfg['layers'], "rng": "philox4x32-10",
+                   "parallelism": "seed-edge data parallel x%d, graph+features replicated" % world},
+        "algorithmic_bytes_per_seed_edge": (samp_bytes + agg_bytes) / b,
+        "achieved_hbm_gbps_whole_step": (samp_bytes + agg_bytes) / b * value / world / 1e9,
+        "roofline": {"bound": "hbm", "kernel": engine.dominant_name(), "achieved": achieved, "peak": 8000.0,
+                     "unit": "GB/s", "frac": achieved / 8000.0, "traffic": engine.measured_traffic(),
+                     "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes},
+    }
+    if train is not None:
+        out["train_step"] = train
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
+
+
 def main():
     args = parse()
+    # a rank that stops making progress must not leave the job hanging: dump where it is and exit
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get('BENCH_WATCHDOG_S', '900')), exit=True)
     import torch
     import torch.distributed as dist
 
@@ -164,9 +199,25 @@ def main():
     err = engine.err_flag.tolist()
     assert err == [0, 0], "sampler reported %s" % err
 
-    # secondary: the training step (sample + forward + backward + gradient all-reduce + Adam)
+    fwd = {"elapsed": elapsed, "probes": [a.elapsed_time(c) for a, c in probes]}
+
+    # secondary: the training step (sample + forward + backward + gradient all-reduce + Adam).
+    # It must never cost the headline number: if it stalls (a collective that never returns),
+    # a timer thread prints the forward-only result and ends the process.
+    import threading
+
+    def give_up():
+        if rank == 0:
+            print(json.dumps(result_line(args, cfg, engine, world, b, fwd,
+                                         {"skipped": "training step did not finish within %d s" % args.train_timeout},
+                                         None)), flush=True)
+        os._exit(0)
+
+    guard = threading.Timer(args.train_timeout, give_up)
+    guard.daemon = True
     train = None
     if args.train_steps > 0:
+        guard.start()
         from graphsage_amd.train import Trainer
         try:
             tr = Trainer(model, lr=1e-2, engine='plan', graph=graph, batch_size=b)
@@ -176,12 +227,19 @@ def main():
         if tr is not None:
             tgt = (torch.arange(b, device=device) % 2).to(torch.float32)
 
+            # one GPU: the step's launches are replayed from a captured HIP graph; several GPUs: plain
+            # stream-ordered launches with the RCCL all-reduce between backward and update
+            step_fn = tr.step_graph if world == 1 else tr.step_device
+
             def tstep(i):
                 k = my_batches[i % len(my_batches)]
-                return tr.step_graph(seeds[k], tgt, walk_ids[k], rng_seed=gen.sampler.seed + 1)
+                return step_fn(seeds[k], tgt, walk_ids[k], rng_seed=gen.sampler.seed + 1)
 
             for i in range(5):
                 tstep(i)
+                if os.environ.get('BENCH_DEBUG'):
+                    torch.cuda.synchronize()
+                    print('[r%d] train warm-up step %d done' % (rank, i), file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -199,37 +257,15 @@ def main():
             assert tr.engine.err_flag.tolist() == [0, 0]
             train = {"value": args.train_steps * b * world / t_el, "unit": "seed edges/s",
                      "ms_per_step": t_el / args.train_steps * 1e3, "steps": args.train_steps,
-                     "what": "sample + fwd + bwd + flat-bucket all-reduce (RCCL for N>1) + Adam, MSE on concat->Dense(1,sigmoid); "
-                             "launches replayed from a captured HIP graph"}
+                     "what": "sample + fwd + bwd + flat-bucket all-reduce (RCCL for N>1) + Adam, MSE on concat->Dense(1,sigmoid)"
+                             + ("; launches replayed from a captured HIP graph" if world == 1 else "")}
 
+    guard.cancel()
     if rank == 0:
-        total_edges = args.steps * b * world
-        value = total_edges / elapsed
-        samp_bytes, agg_bytes = engine.algorithmic_bytes()
-        dom_ms = [a.elapsed_time(c) for a, c in probes]
-        dom_avg = sum(dom_ms) / max(len(dom_ms), 1) * 1e-3
-        dom_bytes = engine.dominant_bytes()
-        achieved = dom_bytes / dom_avg / 1e9 if dom_avg > 0 else 0.0
-        out = {
-            "metric": "seed edges/sec (2-hop sample+aggregate fwd)" if len(cfg['fan']) == 2
-                      else "seed edges/sec (%d-hop sample+aggregate fwd)" % len(cfg['fan']),
-            "value": value, "unit": "seed edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s" % (args.workload, cfg['desc']), "batch_per_gpu": b,
-                       "layer_sizes": cfg['layers'], "rng": "philox4x32-10",
-                       "parallelism": "seed-edge data parallel x%d, graph+features replicated" % world},
-            "algorithmic_bytes_per_seed_edge": (samp_bytes + agg_bytes) / b,
-            "achieved_hbm_gbps_whole_step": (samp_bytes + agg_bytes) / b * value / world / 1e9,
-            "roofline": {"bound": "hbm", "kernel": engine.dominant_name(), "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": engine.measured_traffic(),
-                         "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes},
-        }
-        if train is not None:
-            out["train_step"] = train
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(graph, cfg, heads_u, heads_i, model, args.cpu_batches)
-        print(json.dumps(out))
+            cpu = cpu_baseline(graph, cfg, heads_u, heads_i, model, args.cpu_batches)
+        print(json.dumps(result_line(args, cfg, engine, world, b, fwd, train, cpu)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -80,7 +80,14 @@ class FlatGradBucket:
             return self.flat
         world = dist.get_world_size(group)
         if world > 1:
+            # RCCL ("nccl") collectives are ordered on the stream like kernels.  gloo moves GPU
+            # tensors through host buffers on worker threads; fence the device on both sides of it.
+            fence = self.flat.is_cuda and dist.get_backend(group) == 'gloo'
+            if fence:
+                torch.cuda.synchronize()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if fence:
+                torch.cuda.synchronize()
             self.flat.div_(world)
         return self.flat
 
