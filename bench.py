@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=4096, help='seed edges per step per GPU')
     ap.add_argument('--seed-pool', type=int, default=1 << 20, help='seed edges drawn from the first N edges')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batches', type=int, default=10)
+    ap.add_argument('--cpu-batches', type=int, default=60)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL)')
     ap.add_argument('--train-timeout', type=int, default=300, help='seconds before the train timing is abandoned')
     ap.add_argument('--train-steps', type=int, default=20, help='steps of the secondary fwd+bwd+all-reduce+Adam timing (0: skip)')
