@@ -115,7 +115,7 @@ def result_line(args, cfg, engine, world, b, fwd, train, cpu):
         "algorithmic_bytes_per_seed_edge": (samp_bytes + agg_bytes) / b,
         "achieved_hbm_gbps_whole_step": (samp_bytes + agg_bytes) / b * value / world / 1e9,
         "roofline": {"bound": "hbm", "kernel": engine.dominant_name(), "achieved": achieved, "peak": 8000.0,
-                     "unit": "GB/s", "frac": achieved / 8000.0, "traffic": engine.measured_traffic(),
+                     "unit": "GB/s", "frac": achieved / 8000.0, "traffic": engine.measured_traffic(args.workload),
                      "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes},
     }
     if train is not None:

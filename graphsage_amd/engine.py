@@ -275,9 +275,10 @@ class SageForwardEngine:
         per_type = [children * 4 + children * f[t] * 4 + parents * f[t] * 4 for t in _TYPES]
         return sum(per_type) / len(per_type)
 
-    def measured_traffic(self):
+    def measured_traffic(self, workload):
         """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes,
-        if a measurement for this build was stored under profiles/."""
+        if a measurement of this kernel on this workload (graph, batch, fan-outs)
+        was stored under profiles/; None otherwise."""
         import json
         import os
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'traffic.json')
@@ -288,7 +289,7 @@ class SageForwardEngine:
         name = "sage_fused_kernel" if self.use_fused and all(self.fused_layers) else "gather_mean_kernel"
         if self.walk_kernel:
             name = "sage2_kernel"
-        key = "%s/B%d/%s" % (name, self.batch, 'x'.join(str(n) for n in self.fanouts))
+        key = "%s/%s/B%d/%s" % (workload, name, self.batch, 'x'.join(str(n) for n in self.fanouts))
         return rec.get(key)
 
     # algorithmic bytes of one step, per the accounting used for the roofline

@@ -156,9 +156,13 @@ def hops_to_walks(roots, hops, num_of_walks):
 
 def walk_vectorised(indptr, indices, roots, num_of_walks, rng_seed=None, first_walk=0, tape=None):
     """numpy-vectorised form of ``walk_keyed`` over a CSR, for inputs too large
-    for Python loops.  Exactly one of ``rng_seed`` / ``tape`` is given."""
+    for Python loops.  Exactly one of ``rng_seed`` / ``tape`` is given.
+    ``indices`` may also be any object whose ``[int64 array]`` returns the
+    entries at those positions (attribute ``lazy`` set), for neighbor arrays
+    kept elsewhere than host memory."""
     indptr = np.asarray(indptr)
-    indices = np.asarray(indices)
+    if not getattr(indices, 'lazy', False):
+        indices = np.asarray(indices)
     roots = np.asarray(roots, dtype=np.int64)
     sizes = hop_sizes(num_of_walks)
     offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])

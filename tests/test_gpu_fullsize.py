@@ -1,0 +1,147 @@
+"""Parity at the benchmark's full size (1M users x 100k items, 50M edges,
+fan-outs [25,10], 4096 seed edges per batch) and at sizes past 32-bit offsets --
+needs a GPU.
+
+At these sizes the oracle's Python-loop forms are out of reach, so the checks
+are: the numpy-vectorised oracle walk for every root of a full batch (bit
+exact), the float64 oracle model on a subset of the batch, and size-independent
+properties: two independent kernel paths agree, a link's embedding does not
+depend on the batch it travels in, embeddings have unit length.
+"""
+import numpy as np
+import pytest
+import torch
+
+import graphsage_amd as ga
+from graphsage_amd import kernels, synthetic
+from graphsage_amd.engine import SageForwardEngine
+from oracle import generator as ogen
+from oracle import model as omodel
+from oracle import walker
+
+pytestmark = pytest.mark.gpu
+
+NU, NI, E, F, FAN, B = 1_000_000, 100_000, 50_000_000, 64, [25, 10], 4096
+SEED = 0x9E3779B97F4A7C15
+
+
+@pytest.fixture(scope='module')
+def big(cuda):
+    g, u, it = synthetic.power_law_bipartite(NU, NI, E, F, F, alpha_item=1.1, seed=1234, device=cuda)
+    hu, hi = synthetic.seed_edges(u, it, 1 << 20, seed=0)
+    gen = ga.GraphSAGEGenerator(g, B, FAN, head_node_types=['user', 'item'], seed=1)
+    model = ga.GraphSAGE([32, 32], gen, seed=11).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.1, 0.1)
+    return dict(g=g, hu=hu, hi=hi, model=model, dev=g.device_tensors())
+
+
+def test_full_batch_walks_equal_the_oracle_bit_for_bit(big, cuda):
+    dev = big['dev']
+    seeds = torch.cat([big['hu'][:B], big['hi'][:B]]).contiguous()
+    base = 3 * (1 << 40) + 17
+    hops, err = kernels.sample(dev['indptr'], dev['indices'], seeds, FAN, rng_seed=SEED, walk_id_base=base)
+    assert err.tolist() == [0, 0]
+    indptr, indices = dev['indptr'].cpu().numpy(), dev['indices'].cpu().numpy()
+    assert indices.shape[0] == 2 * E
+    want = walker.walk_vectorised(indptr, indices, seeds.cpu().numpy(), FAN, rng_seed=SEED, first_walk=base)
+    for got, w in zip(hops, want):
+        np.testing.assert_array_equal(got.cpu().numpy(), w)
+    # node types alternate with the hop: user roots -> items -> users
+    h1, h2 = hops
+    assert (h1[:B] >= NU).all() and (h1[B:] < NU).all() and (h2[:B] < NU).all() and (h2[B:] >= NU).all()
+
+
+def test_one_kernel_forward_agrees_with_layered_path_and_oracle_subset(big, cuda):
+    g, model = big['g'], big['model']
+    seeds = torch.cat([big['hu'][B:2 * B], big['hi'][B:2 * B]]).contiguous()
+    walk_ids = torch.cat([2 * torch.arange(B, 2 * B, dtype=torch.int64, device=cuda),
+                          2 * torch.arange(B, 2 * B, dtype=torch.int64, device=cuda) + 1])
+    eng_w = SageForwardEngine(g, model, B)
+    eng_l = SageForwardEngine(g, model, B, walk_kernel=False)
+    eng_u = SageForwardEngine(g, model, B, use_fused=False)
+    assert eng_w.walk_kernel and all(eng_l.fused_layers)
+    out_w = [x.clone() for x in eng_w.forward(seeds, walk_ids, rng_seed=SEED)]
+    out_l = [x.clone() for x in eng_l.forward(seeds, walk_ids, rng_seed=SEED)]
+    out_u = [x.clone() for x in eng_u.forward(seeds, walk_ids, rng_seed=SEED)]
+    assert eng_w.err_flag.tolist() == [0, 0] and eng_l.err_flag.tolist() == [0, 0]
+    for k in range(2):
+        assert torch.isfinite(out_w[k]).all()
+        assert (out_w[k] - out_l[k]).abs().max().item() <= 1e-5          # unit-length rows: scale 1
+        assert (out_w[k] - out_u[k]).abs().max().item() <= 1e-5
+        assert (out_w[k].double().norm(dim=1) - 1).abs().max().item() <= 1e-5
+
+    # float64 oracle on the first links of the batch, from the ids the layered path sampled
+    n = 48
+    hops = [h.cpu().numpy().astype(np.int64) for h in eng_l.hops]
+    sub = [np.concatenate([h[:n], h[B:B + n]]) for h in hops]
+    links = [(int(a), int(b)) for a, b in zip(seeds[:n].tolist(), seeds[B:B + n].tolist())]
+    feats = {'user': big['dev']['user'].cpu().numpy(), 'item': big['dev']['item'].cpu().numpy()}
+    xin = ogen.sample_features_fast(feats, NU, links, sub)
+    plan = omodel.LayerPlan([32, 32], FAN, g.node_feature_sizes)
+    weights = {(l, t): {'w_self': a.w_self.detach().cpu().double(), 'w_neigh': a.w_neigh.detach().cpu().double(),
+                        'bias': a.bias.detach().cpu().double()}
+               for l, per in enumerate(model._aggs) for t, a in per.items()}
+    want = omodel.forward(plan, weights, [torch.from_numpy(np.asarray(x, dtype=np.float64)) for x in xin])
+    for k in range(2):
+        assert (out_w[k][:n].cpu().double() - want[k]).abs().max().item() <= 1e-5
+
+
+def test_embedding_of_a_link_does_not_depend_on_its_batch(big, cuda):
+    g, model = big['g'], big['model']
+    hu, hi = big['hu'], big['hi']
+    ids = lambda lo, hi_: torch.cat([2 * torch.arange(lo, hi_, dtype=torch.int64, device=cuda),
+                                     2 * torch.arange(lo, hi_, dtype=torch.int64, device=cuda) + 1])
+    eng = SageForwardEngine(g, model, B)
+    full = [x.clone() for x in eng.forward(torch.cat([hu[:B], hi[:B]]).contiguous(), ids(0, B), rng_seed=5)]
+    small = SageForwardEngine(g, model, 1000)
+    lo = 1536
+    part = small.forward(torch.cat([hu[lo:lo + 1000], hi[lo:lo + 1000]]).contiguous(), ids(lo, lo + 1000), rng_seed=5)
+    assert torch.equal(part[0], full[0][lo:lo + 1000]) and torch.equal(part[1], full[1][lo:lo + 1000])
+    # another sampling key gives other neighborhoods
+    other = eng.forward(torch.cat([hu[:B], hi[:B]]).contiguous(), ids(0, B), rng_seed=6)
+    assert not torch.equal(other[0], full[0])
+
+
+class _DeviceIndices:
+    """Neighbor array left on the GPU; the oracle fetches the entries it needs."""
+    lazy = True
+
+    def __init__(self, t):
+        self.t = t
+
+    def __getitem__(self, pos):
+        p = torch.from_numpy(np.ascontiguousarray(pos)).to(self.t.device)
+        return self.t[p].cpu().numpy()
+
+
+def test_sampler_addresses_neighbor_arrays_beyond_32_bit_offsets(cuda):
+    """2 000 nodes with ~2.2 M neighbors each: 4.4e9 CSR entries (17.6 GB), so
+    row starts pass 2**32 and degrees pass 2**21."""
+    if torch.cuda.get_device_properties(0).total_memory < 60 * 2 ** 30:
+        pytest.skip("needs about 20 GB of device memory")
+    n_half, deg = 1000, 2_200_003
+    total = 2 * n_half * deg
+    assert total > 2 ** 32
+    indices = torch.empty(total, dtype=torch.int32, device=cuda)
+    gen = torch.Generator(device=cuda)
+    gen.manual_seed(9)
+    chunk = 1 << 28
+    half = n_half * deg                                    # users' neighbors are items and vice versa
+    for a0, a1, lo, hi in ((0, half, n_half, 2 * n_half), (half, total, 0, n_half)):
+        for a in range(a0, a1, chunk):
+            n = min(chunk, a1 - a)
+            indices[a:a + n] = torch.randint(lo, hi, (n,), generator=gen, device=cuda, dtype=torch.int32)
+    indptr = torch.arange(2 * n_half + 1, dtype=torch.int64, device=cuda) * deg
+    roots = torch.tensor([0, 999, 1000, 1999, 1955, 1954, 7, 1500], dtype=torch.int32, device=cuda)
+    hops, err = kernels.sample(indptr, indices, roots, [25, 10], rng_seed=77, walk_id_base=(1 << 50))
+    assert err.tolist() == [0, 0]
+    want = walker.walk_vectorised(indptr.cpu().numpy(), _DeviceIndices(indices), roots.cpu().numpy(), [25, 10],
+                                  rng_seed=77, first_walk=(1 << 50))
+    for got, w in zip(hops, want):
+        np.testing.assert_array_equal(got.cpu().numpy(), w)
+    # the positions drawn really lie past 2**32 for the late rows
+    assert int(indptr[1954]) > 2 ** 32
+    del indices
+    torch.cuda.empty_cache()
