@@ -24,6 +24,8 @@ SIGNATURES = {
     'gs_last_error': (_c.c_char_p, []),
     'gs_sample': (_i32, [_vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32), _i32, _u64, _u64, _vp, _vp,
                          _c.POINTER(_vp), _vp, _vp]),
+    'gs_csr_build_workspace': (_i32, [_i64, _i64, _i64, _c.POINTER(_sz)]),
+    'gs_csr_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     'gs_gather_rows': (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp]),
     'gs_gather_mean_fwd': (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
     'gs_gather_mean_bwd': (_i32, [_vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _vp]),

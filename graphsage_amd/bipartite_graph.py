@@ -86,6 +86,17 @@ class Graph(object):
         g._device = None
         return g
 
+    @classmethod
+    def from_edges_device(cls, node_features, a, b, symmetric=True):
+        """Adjacency built on the GPU from edge columns that already live there
+        (int32 tensors; ``symmetric``: every edge a[i] -- b[i] is entered in both
+        directions, the doubling of ``train_movielens.py:130-132``).  Same CSR as
+        the constructor makes from the same edge array; every id in range is a node."""
+        from . import kernels
+        n = int(node_features['user'].shape[0]) + int(node_features['item'].shape[0])
+        indptr, indices = kernels.build_csr(a, b, n, symmetric=symmetric)
+        return cls.from_csr(node_features, indptr, indices)
+
     @staticmethod
     def _build_csr(edges, n):
         src = edges[0].astype(np.int64, copy=False)

@@ -35,6 +35,31 @@ def hop_sizes(fanouts):
     return out
 
 
+def build_csr(a, b, n_nodes, symmetric=False, sort_chunk=0):
+    """Edge columns (int32 GPU tensors, entry i = edge a[i] -> b[i]; symmetric:
+    followed by the flipped copies) -> (indptr int64[n_nodes+1], indices int32),
+    neighbors in entry order.  Raises ValueError for ids outside [0, n_nodes)."""
+    lib = load()
+    _dev(a, torch.int32, 'a', 1)
+    _dev(b, torch.int32, 'b', 1)
+    if a.numel() != b.numel():
+        raise ValueError("edge columns must have equal length")
+    n_nodes, n_pairs = int(n_nodes), a.numel()
+    if not 0 <= n_nodes < 2 ** 31:
+        raise ValueError("node count must fit int32")
+    need = ctypes.c_size_t(0)
+    check(lib.gs_csr_build_workspace(n_pairs, n_nodes, int(sort_chunk), ctypes.byref(need)), 'gs_csr_build_workspace')
+    ws = torch.empty(max(need.value, 1), dtype=torch.uint8, device=a.device)
+    indptr = torch.empty(n_nodes + 1, dtype=torch.int64, device=a.device)
+    indices = torch.empty(n_pairs * (2 if symmetric else 1), dtype=torch.int32, device=a.device)
+    err = torch.zeros(1, dtype=torch.int32, device=a.device)
+    check(lib.gs_csr_build(ptr(a), ptr(b), n_pairs, 1 if symmetric else 0, n_nodes, ptr(indptr), ptr(indices),
+                           ptr(err), int(sort_chunk), ptr(ws), ws.numel(), stream_handle()), 'gs_csr_build')
+    if int(err.item()):
+        raise ValueError("edge endpoints must be node ids in [0, %d)" % n_nodes)
+    return indptr, indices
+
+
 def sample(indptr, indices, seeds, fanouts, rng_seed=0, walk_id_base=0, walk_ids=None, replay=None,
            err_flag=None):
     """Multi-hop sampling; returns (list of int32 [n_seeds, size_h] tensors, err_flag)."""

@@ -3,9 +3,9 @@
 The reference builds its adjacency with one ``np.where`` scan per node
 (``bipartite_graph.py:53-60``) from an edge list that already holds both
 directions (``train_movielens.py:130-132``); at tens of millions of edges that
-is replaced here by: draw endpoints on the device, append the flipped copy, sort
-stably by source, count.  The result is the same CSR the ``Graph`` constructor
-would make from those edges.
+is replaced here by: draw endpoints on the device and hand both columns to the
+library's adjacency build (``gs_csr_build``: both directions, stable by source).
+The result is the same CSR the ``Graph`` constructor would make from those edges.
 
 Endpoint laws: users uniform; items Zipf(alpha) over item rank (rank 0 most
 popular), truncated to the number of items.  One extra edge per user
@@ -51,21 +51,11 @@ def power_law_bipartite(num_users, num_items, num_edges, feat_user, feat_item, a
     if num_items > num_users:
         raise ValueError("the forced edges cover every item only when num_users >= num_items")
 
-    n = num_users + num_items
-    src = torch.cat([u, it]).to(torch.int64)
-    dst = torch.cat([it, u])
-    deg = torch.bincount(src, minlength=n)
-    indptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
-    torch.cumsum(deg, 0, out=indptr[1:])
-    order = torch.sort(src, stable=True).indices
-    del src
-    indices = dst[order].contiguous()
-    del order, dst
     fgen = torch.Generator(device=device)
     fgen.manual_seed(seed + 1)
     feats = {'user': torch.randn((num_users, feat_user), generator=fgen, device=device, dtype=torch.float32),
              'item': torch.randn((num_items, feat_item), generator=fgen, device=device, dtype=torch.float32)}
-    g = Graph.from_csr(feats, indptr, indices)
+    g = Graph.from_edges_device(feats, u, it, symmetric=True)
     return g, u, it
 
 

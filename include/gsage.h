@@ -43,6 +43,31 @@ int gs_version(void);
 const char *gs_last_error(void);
 
 /*
+ * Adjacency build: edge columns -> CSR.  Replaces Graph.get_neighbor_dict
+ * (bipartite_graph.py:48-60: one np.where scan of the edge array per node) and,
+ * with symmetric != 0, the edge doubling of train_movielens.py:130-132
+ * (edges = concat(edges, flip(edges))).
+ *
+ *   a, b      device int32[n_pairs]: entry i is the edge a[i] -> b[i]; with
+ *             symmetric != 0 the entries are the n_pairs edges a -> b followed by
+ *             the n_pairs edges b -> a, i.e. the reference's doubled edge array
+ *   indptr    device int64[n_nodes+1] (written), indices device int32[entries]
+ *             (written), entries = n_pairs * (symmetric ? 2 : 1): the neighbors of
+ *             v are listed in the order of their entries, duplicates kept -- the
+ *             order of neighbor_dict[v] (bipartite_graph.py:56-58)
+ *   err_flag  device int32[1], zeroed by the caller: becomes 1 if an id lies
+ *             outside [0, n_nodes); indices is then left unwritten
+ *   sort_chunk entries per radix-sort pass, 0 = default (2^30)
+ *   workspace device scratch of at least gs_csr_build_workspace(...) bytes
+ * The result does not depend on timing (no atomics decide positions), so every
+ * GPU of a data-parallel job builds the same replica.
+ */
+int gs_csr_build_workspace(int64_t n_pairs, int64_t n_nodes, int64_t sort_chunk, size_t *bytes);
+int gs_csr_build(const int32_t *a, const int32_t *b, int64_t n_pairs, int symmetric, int64_t n_nodes,
+                 int64_t *indptr, int32_t *indices, int32_t *err_flag, int64_t sort_chunk,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Multi-hop uniform neighbor sampling with replacement over a CSR.
  * Replaces BreadthFirstWalker.run_breadth_first_walk (sampler.py:47-96) and the
  * dict lookups it makes (bipartite_graph.py:62-68); writing hop h of all walks

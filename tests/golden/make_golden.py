@@ -177,6 +177,12 @@ def replay_cases(meta):
         arrays[name + '_edges'] = edges
         arrays[name + '_feat_user'] = feats['user']
         arrays[name + '_feat_item'] = feats['item']
+        # the reference's adjacency itself: neighbor_dict flattened to (row starts, neighbors)
+        nd = built[name].neighbor_dict
+        n_all = feats['user'].shape[0] + feats['item'].shape[0]
+        lists = [list(nd.get(v, [])) for v in range(n_all)]
+        arrays[name + '_adj_indptr'] = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+        arrays[name + '_adj_indices'] = np.asarray([x for l in lists for x in l], dtype=np.int32)
     meta['replay'] = []
     for ci, (gname, ns, b) in enumerate(cases):
         g = built[gname]

@@ -34,7 +34,20 @@ def big(cuda):
     for p in model.parameters():
         if p.dim() == 1:
             p.data.uniform_(-0.1, 0.1)
-    return dict(g=g, hu=hu, hi=hi, model=model, dev=g.device_tensors())
+    return dict(g=g, u=u, it=it, hu=hu, hi=hi, model=model, dev=g.device_tensors())
+
+
+def test_adjacency_of_100m_entries_equals_a_stable_sort_by_source(big, cuda):
+    dev = big['dev']
+    hu = big['u'].to(torch.int64)
+    hi = big['it'].to(torch.int64)
+    src = torch.cat([hu, hi])
+    dst = torch.cat([big['it'], big['u']])
+    order = torch.sort(src, stable=True).indices
+    assert torch.equal(dev['indices'], dst[order])
+    deg = torch.bincount(src, minlength=NU + NI)
+    assert torch.equal(dev['indptr'][1:], torch.cumsum(deg, 0)) and int(dev['indptr'][0]) == 0
+    assert int(deg.min()) >= 1
 
 
 def test_full_batch_walks_equal_the_oracle_bit_for_bit(big, cuda):

@@ -34,6 +34,61 @@ def csr_of(g):
     return np.asarray(g.indptr), np.asarray(g.indices)
 
 
+# ---------------------------------------------------------- adjacency build ----
+
+@pytest.mark.parametrize('name', ['g_small', 'g_mid'])
+@pytest.mark.parametrize('chunk', [0, 1, 7, 1000])
+def test_device_adjacency_build_equals_reference_neighbor_lists(golden, cuda, name, chunk):
+    """gs_csr_build against the reference's neighbor_dict (flattened in the
+    fixtures); chunk sizes below the edge count exercise the multi-pass append."""
+    arrays, _ = golden
+    feats, nodes, edges = golden_graph_parts(arrays, name)
+    n = feats['user'].shape[0] + feats['item'].shape[0]
+    a = torch.from_numpy(edges[0].astype(np.int32)).to(cuda)
+    b = torch.from_numpy(edges[1].astype(np.int32)).to(cuda)
+    indptr, indices = kernels.build_csr(a, b, n, symmetric=False, sort_chunk=chunk)
+    np.testing.assert_array_equal(indptr.cpu().numpy(), arrays[name + '_adj_indptr'])
+    np.testing.assert_array_equal(indices.cpu().numpy(), arrays[name + '_adj_indices'])
+    # the fixture's edge array is [pairs, flipped pairs]: the symmetric form takes the first half
+    half = edges.shape[1] // 2
+    np.testing.assert_array_equal(edges[:, half:], edges[::-1, :half])
+    indptr2, indices2 = kernels.build_csr(a[:half].contiguous(), b[:half].contiguous(), n, symmetric=True,
+                                          sort_chunk=chunk)
+    assert torch.equal(indptr2, indptr) and torch.equal(indices2, indices)
+    g = ga.Graph.from_edges_device({k: torch.from_numpy(v).to(cuda) for k, v in feats.items()},
+                                   a[:half].contiguous(), b[:half].contiguous())
+    assert torch.equal(g.indptr, indptr) and g.num_users == feats['user'].shape[0]
+
+
+def test_device_adjacency_build_edge_cases(cuda):
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=cuda)
+    indptr, indices = kernels.build_csr(i32([]), i32([]), 5)
+    assert indptr.tolist() == [0] * 6 and indices.numel() == 0
+    indptr, indices = kernels.build_csr(i32([]), i32([]), 0)
+    assert indptr.tolist() == [0]
+    # duplicates kept, isolated nodes get empty rows, order = entry order
+    indptr, indices = kernels.build_csr(i32([3, 0, 3, 3, 0]), i32([1, 4, 1, 0, 2]), 6)
+    assert indptr.tolist() == [0, 2, 2, 2, 5, 5, 5] and indices.tolist() == [4, 2, 1, 1, 0]
+    for bad in ([0, 6], [0, -1]):
+        with pytest.raises(ValueError):
+            kernels.build_csr(i32([0, 1]), i32(bad), 6)
+        with pytest.raises(ValueError):
+            kernels.build_csr(i32(bad), i32([0, 1]), 6, symmetric=True)
+    # a large random case against numpy's stable sort, several chunk sizes, one hub row
+    rng = np.random.default_rng(4)
+    n, e = 5000, 300_000
+    src = rng.integers(0, n, e).astype(np.int32)
+    src[rng.integers(0, e, 60_000)] = 17
+    dst = rng.integers(0, n, e).astype(np.int32)
+    order = np.argsort(src, kind='stable')
+    want_ptr = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=n))])
+    for chunk in (0, 4096, 99_999):
+        indptr, indices = kernels.build_csr(torch.from_numpy(src).to(cuda), torch.from_numpy(dst).to(cuda), n,
+                                            sort_chunk=chunk)
+        np.testing.assert_array_equal(indptr.cpu().numpy(), want_ptr)
+        np.testing.assert_array_equal(indices.cpu().numpy(), dst[order])
+
+
 # ---------------------------------------------------------------- sampler ----
 
 @pytest.mark.parametrize('case', range(7))

@@ -31,6 +31,9 @@ def test_csr_matches_reference_neighbor_lists(golden):
         parts = golden_graph_parts(arrays, name)
         g, o = ga.Graph(*parts), OracleGraph(*parts)
         assert g.indptr.dtype == np.int64 and g.indices.dtype == np.int32
+        # the reference's own neighbor_dict, flattened when the fixtures were made
+        np.testing.assert_array_equal(g.indptr, arrays[name + '_adj_indptr'])
+        np.testing.assert_array_equal(g.indices, arrays[name + '_adj_indices'])
         for node, neigh in o.neighbor_dict.items():
             assert g.get_neighbors_from_node(node) == neigh
         assert g.num_nodes == o.num_nodes and g.num_edges == o.num_edges
