@@ -132,6 +132,20 @@ class LinkSequence:
             batch_feats = self._sample_features(head_ids, batch_num)
         return batch_feats, batch_targets
 
+    def roots(self, batch_num):
+        """The batch as the kernels take it, without sampling: (roots int32[2b] on
+        the GPU -- sources then destinations --, walk ids int64[2b], sampling key,
+        targets).  Only for sequences made by ``GraphSAGEGenerator.flow``."""
+        if not self._indexed:
+            raise TypeError("this sequence's sampling function does not key draws by link")
+        start_idx = self.batch_size * batch_num
+        if start_idx >= self.data_size:
+            raise IndexError("Mapper: batch_num larger than length of data")
+        batch_indices = self.indices[start_idx:start_idx + self.batch_size]
+        head_ids = [self.ids[ii] for ii in batch_indices]
+        seeds, walk_ids, key = self._sample_features.roots(head_ids, batch_indices, self.epoch)
+        return seeds, walk_ids, key, (None if self.targets is None else self.targets[batch_indices])
+
     def __iter__(self):
         for b in range(len(self)):
             yield self[b]
@@ -212,6 +226,10 @@ class _IndexedSampler:
     def __call__(self, head_links, batch_num, link_index=None, epoch=0):
         return self._gen._sample(head_links, link_index, epoch)
 
+    def roots(self, head_links, link_index, epoch):
+        roots, walk_ids, _ = self._gen._roots(head_links, link_index)
+        return roots, walk_ids, _mix64(self._gen._base_seed(), epoch)
+
 
 class GraphSAGEGenerator(BatchedLinkGenerator):
     def __init__(self, Graph, batch_size, num_samples, head_node_types=None, seed=None):
@@ -264,7 +282,9 @@ class GraphSAGEGenerator(BatchedLinkGenerator):
         sampler's running counter, like a global random stream advancing."""
         return self._sample(head_links, None, 0)
 
-    def _sample(self, head_links, link_index, epoch):
+    def _roots(self, head_links, link_index):
+        """(roots on the GPU, walk ids or None, batch size) after the membership
+        checks the reference makes through its dict lookups."""
         import torch
         from ._lib import require_gpu
         dev = require_gpu()
@@ -282,6 +302,11 @@ class GraphSAGEGenerator(BatchedLinkGenerator):
         if link_index is not None:
             li = np.asarray(link_index, dtype=np.int64)
             walk_ids = torch.from_numpy(np.concatenate([2 * li, 2 * li + 1])).to(dev)
+        return roots, walk_ids, b
+
+    def _sample(self, head_links, link_index, epoch):
+        roots, walk_ids, b = self._roots(head_links, link_index)
+        if walk_ids is not None:
             self.sampler.seed = _mix64(self._base_seed(), epoch)
         hops = self.sampler.sample_device(roots, walk_ids=walk_ids)
         slot_ids = [roots[:b].reshape(b, 1), roots[b:].reshape(b, 1)]

@@ -17,6 +17,7 @@ gloo) and the autograd path.
 """
 import math
 
+import numpy as np
 import torch
 
 __all__ = ['LinkHead', 'FlatGradBucket', 'Adam', 'Trainer']
@@ -253,6 +254,88 @@ class Trainer:
             self.opt.step(launch=False)                  # sets the device-side rate for this step
             self._graph.replay()
         return self._head_step.loss, self._head_step.pred.reshape(-1, 1)
+
+    # -- Keras-style loops over a LinkSequence ------------------------------------------
+    def _metrics(self):
+        from .metrics import AUC, BinaryAccuracy, RootMeanSquaredError
+        return [RootMeanSquaredError(), BinaryAccuracy(), AUC()]
+
+    def _common_batches(self, seq):
+        """Number of batches every rank can take (a collective per step needs all
+        ranks to make the same number of steps)."""
+        import torch.distributed as dist
+        n = len(seq)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            t = torch.tensor([n], dtype=torch.int64, device=self.bucket.flat.device)
+            if t.is_cuda and dist.get_backend(self.group) == 'gloo':
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            n = int(t.item())
+        return n
+
+    def fit(self, train_seq, validation_data=None, epochs=1, verbose=1):
+        """The loop ``Model.fit(train_gen, validation_data=test_gen, epochs=...)``
+        runs in the reference (``train_movielens.py:200-207``): one optimisation
+        step per batch, the compiled metrics (``:187-189``) accumulated over the
+        epoch, validation after it, ``on_epoch_end`` of the sequence.  Full
+        batches go through the static plan when there is one, short ones through
+        autograd.  Returns {'loss': [...], 'auc': [...], 'val_loss': [...], ...}."""
+        history = {}
+        dev = self.bucket.flat.device
+        for epoch in range(epochs):
+            mets = self._metrics()
+            loss_sum, seen = torch.zeros((), dtype=torch.float64, device=dev), 0
+            for i in range(self._common_batches(train_seq)):
+                planned = self.engine is not None and hasattr(train_seq, 'roots') and train_seq._indexed
+                if planned:
+                    seeds, walk_ids, key, y = train_seq.roots(i)
+                    planned = seeds.numel() == 2 * self.engine.batch
+                if planned:
+                    y_dev = torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)
+                    loss, pred = self.step_device(seeds, y_dev, walk_ids, key)
+                    pred = pred.clone()
+                else:
+                    batch, y = train_seq[i]
+                    y_dev = torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)
+                    loss, pred = self.step(batch, y_dev)
+                n = y_dev.numel()
+                loss_sum += loss.detach().double().reshape(()) * n
+                seen += n
+                for m in mets:
+                    m.update_state(y_dev, pred)
+            logs = {'loss': float(loss_sum) / max(seen, 1)}
+            logs.update({m.name: m.result() for m in mets})
+            if validation_data is not None:
+                logs.update({'val_' + k: v for k, v in self.evaluate(validation_data).items()})
+            for k, v in logs.items():
+                history.setdefault(k, []).append(v)
+            if verbose:
+                print("Epoch %d/%d - %s" % (epoch + 1, epochs, " - ".join("%s: %.4f" % kv for kv in logs.items())))
+            train_seq.on_epoch_end()
+        return history
+
+    @torch.no_grad()
+    def evaluate(self, seq):
+        """Loss and metrics of the current weights over a sequence (no update)."""
+        dev = self.bucket.flat.device
+        mets = self._metrics()
+        loss_sum, seen = torch.zeros((), dtype=torch.float64, device=dev), 0
+        for i in range(len(seq)):
+            batch, y = seq[i]
+            y_dev = torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)
+            loss, pred = self.loss(batch, y_dev)
+            loss_sum += loss.double() * y_dev.numel()
+            seen += y_dev.numel()
+            for m in mets:
+                m.update_state(y_dev, pred)
+        out = {'loss': float(loss_sum) / max(seen, 1)}
+        out.update({m.name: m.result() for m in mets})
+        return out
+
+    @torch.no_grad()
+    def predict(self, seq):
+        """Scores of every link of a sequence, in sequence order: float32 [n, 1]."""
+        return torch.cat([self.head(self.model(seq[i][0])) for i in range(len(seq))])
 
     def step(self, batch, targets):
         self.bucket.zero()

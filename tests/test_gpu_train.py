@@ -199,3 +199,61 @@ def test_graph_replayed_steps_equal_eager_steps(cuda):
     assert l0 == l1, (l0, l1)                                # same kernels, same order: same bits
     for a, c in zip(p0, p1):
         assert torch.equal(a, c)
+
+
+# ------------------------------------------- MovieLens-format run end to end ----
+
+def _movielens_files(tmp_path, n_users=300, n_movies=120, seed=0):
+    rng = np.random.default_rng(seed)
+    genres = ['Action', 'Comedy', 'Drama', 'Horror', 'Romance', 'Sci-Fi', "Children's"]
+    ages = [1, 18, 25, 35, 45, 50, 56]
+    with open(tmp_path / 'users.dat', 'w') as fh:
+        for u in range(1, n_users + 1):
+            fh.write("%d::%s::%d::%d::%05d\n" % (u, 'FM'[rng.integers(2)], ages[rng.integers(7)], rng.integers(21),
+                                                 rng.integers(99999)))
+    with open(tmp_path / 'movies.dat', 'w', encoding='iso-8859-1') as fh:
+        for m in range(1, n_movies + 1):
+            k = rng.integers(1, 4)
+            fh.write("%d::Film \xe9 %d (1999)::%s\n" % (m, m, '|'.join(rng.choice(genres, k, replace=False))))
+    return str(tmp_path / 'users.dat'), str(tmp_path / 'movies.dat')
+
+
+def test_movielens_format_fit_learns_and_both_step_paths_agree(cuda, tmp_path):
+    from graphsage_amd import metrics, movielens
+    from graphsage_amd.link_utils import link_classification
+    users, movies = _movielens_files(tmp_path)
+    ratings = movielens.synthetic_ratings(users, movies, 12_000, seed=1)
+    data = movielens.load_movielens(users, movies, ratings, pad_to=32)
+    g = ga.Graph(node_features=data['node_features'], nodes=data['nodes'], edges=data['edges'])
+    links = [tuple(l) for l in data['links'].tolist()]
+    tr_idx, te_idx = movielens.train_test_split(len(links), 0.7, 0.3, seed=0)
+
+    def run(engine, epochs):
+        gen = ga.GraphSAGEGenerator(g, 100, [8, 4], head_node_types=['user', 'item'], seed=3)
+        train = gen.flow([links[i] for i in tr_idx], targets=data['labels'][tr_idx], shuffle=True, seed=4)
+        test = gen.flow([links[i] for i in te_idx], targets=data['labels'][te_idx])
+        model = ga.GraphSAGE([32, 32], gen, seed=7)
+        _, x_out = model.in_out_tensors()
+        head = link_classification(edge_embedding_method='concat')(x_out, seed=8)
+        t = Trainer(model, head=head, lr=1e-2, graph=g, batch_size=100, engine=engine)
+        return t, t.fit(train, validation_data=test, epochs=epochs, verbose=0), test
+
+    t_plan, h_plan, test = run('plan', 4)
+    assert t_plan.engine is not None
+    assert h_plan['loss'][-1] < h_plan['loss'][0] and h_plan['val_auc'][-1] > 0.6, h_plan
+    assert set(h_plan) >= {'loss', 'auc', 'binary_accuracy', 'root_mean_squared_error', 'val_loss', 'val_auc'}
+    # same run through autograd: the two step paths are the same computation
+    t_auto, h_auto, _ = run('autograd', 1)
+    assert t_auto.engine is None
+    assert abs(h_auto['loss'][0] - h_plan['loss'][0]) <= 1e-4 * h_plan['loss'][0]
+    # the streaming AUC equals the oracle's restatement of the Keras metric on the same scores
+    pred = t_plan.predict(test).cpu().numpy()
+    y = np.concatenate([test[i][1] for i in range(len(test))])
+    m = metrics.AUC()
+    m.update_state(y[:500], torch.from_numpy(pred[:500]).to(cuda))
+    m.update_state(y[500:], torch.from_numpy(pred[500:]).to(cuda))
+    assert abs(m.result() - omodel.keras_auc(y, pred)) < 1e-6
+    ev = t_plan.evaluate(test)
+    assert abs(ev['auc'] - h_plan['val_auc'][-1]) < 1e-9
+    with pytest.raises(NotImplementedError):
+        link_classification(edge_embedding_method='ip')
