@@ -67,6 +67,40 @@ class GroupMean(torch.autograd.Function):
         return g_x.reshape(shape), None, None
 
 
+class GatherMax(torch.autograd.Function):
+    """max over the sampled children of each parent, rows taken from a feature
+    table by node id; the table is an input of the model and gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, feat, child_ids, n_parents, n_child, id_offset):
+        if feat.requires_grad:
+            raise NotImplementedError("the max aggregator has no gradient into a feature table")
+        return kernels.gather_max(feat, child_ids, n_parents, n_child, id_offset)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None, None, None, None
+
+
+class GroupMax(torch.autograd.Function):
+    """max over axis 1 of a dense (n_parents, n_child, F) tensor; ties share the
+    gradient evenly."""
+
+    @staticmethod
+    def forward(ctx, x, n_parents, n_child):
+        x2 = x.reshape(n_parents * n_child, -1)
+        out = kernels.gather_max(x2, None, n_parents, n_child)
+        ctx.save_for_backward(x2, out)
+        ctx.meta = (x.shape, int(n_child))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, out = ctx.saved_tensors
+        shape, n_child = ctx.meta
+        return kernels.group_max_bwd(g.contiguous(), x2, out, n_child).reshape(shape), None, None
+
+
 class SageProject(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_self, x_mean, w_self, w_neigh, bias, act):

@@ -1,4 +1,4 @@
-// Kernel 2: feature-row gather and fused gather-mean (forward and backward).
+// Kernel 2: feature-row gather and fused gather-mean / gather-max (forward and backward).
 //
 // A feature row of F floats is covered by a "row group" of G lanes, each lane
 // holding VEC consecutive floats (VEC = 4 when F and the base pointers allow
@@ -11,6 +11,11 @@
 // child order inside registers and no cross-lane reduction is needed.  The
 // child ids of the block's tile of parents are staged in LDS with one coalesced
 // pass and read back as broadcasts.
+//
+// gather-max is the same walk with max in place of add (the reference's other
+// aggregation, utils.py:110-111); its backward hands the parent's gradient to
+// the children that attain the maximum, split evenly between ties -- the rule of
+// TensorFlow's reduce_max gradient, which matters after a relu (many exact zeros).
 #include "gs_common.h"
 
 namespace {
@@ -32,6 +37,13 @@ template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
 __device__ __forceinline__ void vadd(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __device__ __forceinline__ void vadd(float2 &a, const float2 &b) { a.x += b.x; a.y += b.y; }
 __device__ __forceinline__ void vadd(float &a, const float &b) { a += b; }
+__device__ __forceinline__ void vmax(float4 &a, const float4 &b) { a.x = fmaxf(a.x, b.x); a.y = fmaxf(a.y, b.y); a.z = fmaxf(a.z, b.z); a.w = fmaxf(a.w, b.w); }
+__device__ __forceinline__ void vmax(float2 &a, const float2 &b) { a.x = fmaxf(a.x, b.x); a.y = fmaxf(a.y, b.y); }
+__device__ __forceinline__ void vmax(float &a, const float &b) { a = fmaxf(a, b); }
+template <int VEC> __device__ __forceinline__ typename Vec<VEC>::type vfill(float f);
+template <> __device__ __forceinline__ float4 vfill<4>(float f) { return make_float4(f, f, f, f); }
+template <> __device__ __forceinline__ float2 vfill<2>(float f) { return make_float2(f, f); }
+template <> __device__ __forceinline__ float vfill<1>(float f) { return f; }
 __device__ __forceinline__ float4 vdiv(const float4 &a, float d) { return make_float4(a.x / d, a.y / d, a.z / d, a.w / d); }
 __device__ __forceinline__ float2 vdiv(const float2 &a, float d) { return make_float2(a.x / d, a.y / d); }
 __device__ __forceinline__ float vdiv(const float &a, float d) { return a / d; }
@@ -55,7 +67,7 @@ void gather_rows_kernel(const float *__restrict__ feat, int64_t n_rows, int F, i
     }
 }
 
-template <int VEC>
+template <int VEC, bool MAXOP>
 __global__ __launch_bounds__(kThreads)
 void gather_mean_kernel(const float *__restrict__ feat, int64_t n_rows, int F, int64_t id_offset,
                         const int32_t *__restrict__ child_ids, int64_t n_parents, int n_child,
@@ -82,23 +94,29 @@ void gather_mean_kernel(const float *__restrict__ feat, int64_t n_rows, int F, i
             const int32_t *my_ids = stage_ids ? s_ids + pl * n_child
                                               : (child_ids ? child_ids + p * n_child : nullptr);
             for (int c = lig; c < fv; c += G) {
-                V acc = vzero<VEC>();
+                // identity of the reduction for the slots past n_child; a row outside the table counts as zeros
+                const V ident = MAXOP ? vfill<VEC>(-INFINITY) : vzero<VEC>();
+                V acc = ident;
                 for (int j0 = 0; j0 < n_child; j0 += kUnroll) {
                     V v[kUnroll];
 #pragma unroll
                     for (int u = 0; u < kUnroll; ++u) {
                         const int j = j0 + u;
-                        v[u] = vzero<VEC>();
+                        v[u] = ident;
                         if (j < n_child) {
                             const int64_t row = my_ids ? (int64_t)my_ids[j] - id_offset : p * n_child + j;
+                            v[u] = vzero<VEC>();
                             if ((uint64_t)row < (uint64_t)n_rows)
                                 v[u] = reinterpret_cast<const V *>(feat + row * F)[c];
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) vadd(acc, v[u]);
+                    for (int u = 0; u < kUnroll; ++u) {
+                        if (MAXOP) vmax(acc, v[u]);
+                        else vadd(acc, v[u]);
+                    }
                 }
-                reinterpret_cast<V *>(out + p * F)[c] = vdiv(acc, denom);
+                reinterpret_cast<V *>(out + p * F)[c] = MAXOP ? acc : vdiv(acc, denom);
             }
         }
     }
@@ -133,6 +151,27 @@ void gather_mean_bwd_kernel(const float *__restrict__ g_mean, const int32_t *__r
                 }
             }
         }
+    }
+}
+
+// Backward of the dense group max: child j of parent p gets g[p] where x[j] equals the
+// maximum, divided by the number of children that do.
+__global__ __launch_bounds__(kThreads)
+void group_max_bwd_kernel(const float *__restrict__ g_max, const float *__restrict__ x,
+                          const float *__restrict__ out_max, int64_t n_parents, int n_child, int F,
+                          float *__restrict__ g_x) {
+    const int64_t total = n_parents * F;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
+        const int64_t p = i / F;
+        const int f = (int)(i - p * F);
+        const float m = out_max[i];
+        const float *xs = x + p * n_child * F + f;
+        int ties = 0;
+        for (int j = 0; j < n_child; ++j) ties += xs[(int64_t)j * F] == m;
+        const float share = ties ? g_max[i] / (float)ties : 0.f;
+        float *gx = g_x + p * n_child * F + f;
+        for (int j = 0; j < n_child; ++j) gx[(int64_t)j * F] = xs[(int64_t)j * F] == m ? share : 0.f;
     }
 }
 
@@ -175,15 +214,17 @@ extern "C" int gs_gather_rows(const float *feat, int64_t n_rows, int F, int64_t 
     return gs::check_launch("gs_gather_rows");
 }
 
-extern "C" int gs_gather_mean_fwd(const float *feat, int64_t n_rows, int F, int64_t id_offset,
-                                  const int32_t *child_ids, int64_t n_parents, int n_child,
-                                  float *out_mean, void *stream) {
+namespace {
+
+template <bool MAXOP>
+int gather_reduce_fwd(const char *what, const float *feat, int64_t n_rows, int F, int64_t id_offset,
+                      const int32_t *child_ids, int64_t n_parents, int n_child, float *out_mean, void *stream) {
     if (n_parents == 0) return GS_OK;
-    if (!feat || !out_mean) return gs::fail(GS_EINVAL, "gs_gather_mean_fwd: null pointer argument");
+    if (!feat || !out_mean) return gs::fail(GS_EINVAL, "%s: null pointer argument", what);
     if (F < 1 || n_child < 1 || n_parents < 0 || n_rows < 0)
-        return gs::fail(GS_EINVAL, "gs_gather_mean_fwd: F=%d n_child=%d n_parents=%lld n_rows=%lld", F, n_child, (long long)n_parents, (long long)n_rows);
+        return gs::fail(GS_EINVAL, "%s: F=%d n_child=%d n_parents=%lld n_rows=%lld", what, F, n_child, (long long)n_parents, (long long)n_rows);
     if (!child_ids && n_parents * (int64_t)n_child > n_rows)
-        return gs::fail(GS_EINVAL, "gs_gather_mean_fwd: dense groups need n_parents*n_child <= n_rows");
+        return gs::fail(GS_EINVAL, "%s: dense groups need n_parents*n_child <= n_rows", what);
     const int vec = pick_vec(F, feat, out_mean);
     const int lg = group_log2(F, vec);
     const int groups = kThreads >> lg;
@@ -194,10 +235,38 @@ extern "C" int gs_gather_mean_fwd(const float *feat, int64_t n_rows, int F, int6
     const size_t lds = stage ? (size_t)tile * n_child * sizeof(int32_t) : 0;
     const unsigned grid = grid_for(n_parents, tile);
     hipStream_t s = (hipStream_t)stream;
-    if (vec == 4) hipLaunchKernelGGL(gather_mean_kernel<4>, dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
-    else if (vec == 2) hipLaunchKernelGGL(gather_mean_kernel<2>, dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
-    else hipLaunchKernelGGL(gather_mean_kernel<1>, dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
-    return gs::check_launch("gs_gather_mean_fwd");
+    if (vec == 4) hipLaunchKernelGGL((gather_mean_kernel<4, MAXOP>), dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
+    else if (vec == 2) hipLaunchKernelGGL((gather_mean_kernel<2, MAXOP>), dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
+    else hipLaunchKernelGGL((gather_mean_kernel<1, MAXOP>), dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
+    return gs::check_launch(what);
+}
+
+}  // namespace
+
+extern "C" int gs_gather_mean_fwd(const float *feat, int64_t n_rows, int F, int64_t id_offset,
+                                  const int32_t *child_ids, int64_t n_parents, int n_child,
+                                  float *out_mean, void *stream) {
+    return gather_reduce_fwd<false>("gs_gather_mean_fwd", feat, n_rows, F, id_offset, child_ids, n_parents, n_child,
+                                    out_mean, stream);
+}
+
+extern "C" int gs_gather_max_fwd(const float *feat, int64_t n_rows, int F, int64_t id_offset,
+                                 const int32_t *child_ids, int64_t n_parents, int n_child,
+                                 float *out_max, void *stream) {
+    return gather_reduce_fwd<true>("gs_gather_max_fwd", feat, n_rows, F, id_offset, child_ids, n_parents, n_child,
+                                   out_max, stream);
+}
+
+extern "C" int gs_group_max_bwd(const float *g_max, const float *x, const float *out_max, int64_t n_parents,
+                                int n_child, int F, float *g_x, void *stream) {
+    if (n_parents == 0) return GS_OK;
+    if (!g_max || !x || !out_max || !g_x) return gs::fail(GS_EINVAL, "gs_group_max_bwd: null pointer argument");
+    if (F < 1 || n_child < 1 || n_parents < 0)
+        return gs::fail(GS_EINVAL, "gs_group_max_bwd: F=%d n_child=%d n_parents=%lld", F, n_child, (long long)n_parents);
+    const unsigned grid = grid_for(n_parents * (int64_t)F, kThreads, 256 * 64);
+    hipLaunchKernelGGL(group_max_bwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, g_max, x, out_max,
+                       n_parents, n_child, F, g_x);
+    return gs::check_launch("gs_group_max_bwd");
 }
 
 extern "C" int gs_gather_mean_bwd(const float *g_mean, const int32_t *child_ids, int64_t n_parents,

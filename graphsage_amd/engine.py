@@ -68,6 +68,10 @@ class SageForwardEngine:
         self._hop_ptrs = None
         self.probes = None           # list to receive (start, end) events around the dominant launches
         self.seeds_buf = torch.zeros(2 * b, dtype=torch.int32, device=device)   # placeholder roots
+        # the fused kernels implement the mean aggregator; 'max' runs gather + reduce + projection
+        self.agg_max = getattr(model, 'agg_option', 'mean') == 'max'
+        use_fused = bool(use_fused) and not self.agg_max
+        self._reduce = kernels.gather_max if self.agg_max else kernels.gather_mean
         self.use_fused = use_fused
         self.fused_layers = [self._fused_ok(layer) and use_fused for layer in range(self.n_hops)]
         self._fused_calls = {}
@@ -115,13 +119,13 @@ class SageForwardEngine:
                 dst = self.x_mean[0][t][r0:r0 + n]
                 if h + 1 < self.n_hops:
                     _, c0, cn = self.where[s + 2]
-                    kernels.gather_mean(self.x_self[other[t]][c0:c0 + cn], None, n, self.fanouts[h], out=dst)
+                    self._reduce(self.x_self[other[t]][c0:c0 + cn], None, n, self.fanouts[h], out=dst)
                 else:
                     feat, off = self.tables[other[t]]
                     if self.probes is not None:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                    kernels.gather_mean(feat, self._slot_ids(seeds, h + 1, side), n, self.fanouts[h], off, out=dst)
+                    self._reduce(feat, self._slot_ids(seeds, h + 1, side), n, self.fanouts[h], off, out=dst)
                     if self.probes is not None:
                         e1.record()
                         self.probes.append((e0, e1))
@@ -132,7 +136,7 @@ class SageForwardEngine:
                         if h > self.n_hops - 1 - layer:
                             continue
                         _, c0, cn = self.where[s + 2]
-                        kernels.gather_mean(self.h[layer - 1][other[t]][c0:c0 + cn], None, n, self.fanouts[h],
+                        self._reduce(self.h[layer - 1][other[t]][c0:c0 + cn], None, n, self.fanouts[h],
                                             out=self.x_mean[layer][t][r0:r0 + n])
             for t in _TYPES:
                 agg = m._aggs[layer][t]

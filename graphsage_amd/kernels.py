@@ -112,7 +112,33 @@ def gather_rows(feat, ids, id_offset=0, out=None):
     return out
 
 
-def gather_mean(feat, child_ids, n_parents, n_child, id_offset=0, out=None):
+def gather_max(feat, child_ids, n_parents, n_child, id_offset=0, out=None):
+    """Per-feature maximum over each parent's children; arguments as gather_mean."""
+    return gather_mean(feat, child_ids, n_parents, n_child, id_offset, out, _entry='gs_gather_max_fwd')
+
+
+def group_max_bwd(g_max, x, out_max, n_child, g_x=None):
+    """Gradient of the dense group max w.r.t. the children x [n_parents*n_child, F]."""
+    lib = load()
+    _dev(g_max, torch.float32, 'g_max', 2)
+    _dev(x, torch.float32, 'x', 2)
+    _dev(out_max, torch.float32, 'out_max', 2)
+    n_parents, f = g_max.shape
+    if out_max.shape != g_max.shape or x.shape != (n_parents * n_child, f):
+        raise ValueError("shapes: g_max %s, out_max %s, x %s for n_child %d"
+                         % (tuple(g_max.shape), tuple(out_max.shape), tuple(x.shape), n_child))
+    if g_x is None:
+        g_x = torch.empty_like(x)
+    else:
+        _dev(g_x, torch.float32, 'g_x')
+        if g_x.numel() != x.numel():
+            raise ValueError("g_x has %d elements, %d needed" % (g_x.numel(), x.numel()))
+    check(lib.gs_group_max_bwd(ptr(g_max), ptr(x), ptr(out_max), n_parents, int(n_child), f, ptr(g_x),
+                               stream_handle()), 'gs_group_max_bwd')
+    return g_x
+
+
+def gather_mean(feat, child_ids, n_parents, n_child, id_offset=0, out=None, _entry='gs_gather_mean_fwd'):
     """child_ids None: dense groups (parent p owns rows p*n_child .. of feat)."""
     lib = load()
     _dev(feat, torch.float32, 'feat', 2)
@@ -129,8 +155,8 @@ def gather_mean(feat, child_ids, n_parents, n_child, id_offset=0, out=None):
         _dev(out, torch.float32, 'out')
         if out.numel() != n_parents * f:
             raise ValueError("out has %d elements, %d needed" % (out.numel(), n_parents * f))
-    check(lib.gs_gather_mean_fwd(ptr(feat), feat.shape[0], f, int(id_offset), ptr(child_ids), n_parents,
-                                 n_child, ptr(out), stream_handle()), 'gs_gather_mean_fwd')
+    check(getattr(lib, _entry)(ptr(feat), feat.shape[0], f, int(id_offset), ptr(child_ids), n_parents,
+                               n_child, ptr(out), stream_handle()), _entry)
     return out
 
 

@@ -144,11 +144,13 @@ class GraphSAGE:
             j = neigh_indices[0]
             m = x_self[i].shape[0]
             n = self.n_samples[self._depths[i]]
-            if j < len(alive):            # neighbor slot is itself gathered: mean of those rows
-                x_mean = _ag.GroupMean.apply(x_self[j].reshape(m, n, -1), m, n)
-            else:                          # deepest slot: rows are summed as they are fetched
+            group, gather = ((_ag.GroupMax, _ag.GatherMax) if self.agg_option == 'max'
+                             else (_ag.GroupMean, _ag.GatherMean))
+            if j < len(alive):            # neighbor slot is itself gathered: mean (max) of those rows
+                x_mean = group.apply(x_self[j].reshape(m, n, -1), m, n)
+            else:                          # deepest slot: rows are reduced as they are fetched
                 feat, off = batch.table(self.subtree_schema[j][0])
-                x_mean = _ag.GatherMean.apply(feat, batch.ids[j].reshape(-1), m, n, off)
+                x_mean = gather.apply(feat, batch.ids[j].reshape(-1), m, n, off)
             agg = self._aggs[0][node_type]
             out.append(agg.project(x_self[i], x_mean).reshape(b, m // b, agg.output_dim))
         return out

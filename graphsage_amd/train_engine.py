@@ -19,6 +19,9 @@ from .engine import SageForwardEngine, _TYPES
 class SageTrainEngine(SageForwardEngine):
     def __init__(self, graph, model, batch_size):
         super().__init__(graph, model, batch_size, use_fused=True, walk_kernel=False)
+        if self.agg_max:
+            raise kernels._lib.GsageError("the training plan covers the mean aggregator; agg_option='max' trains "
+                                          "through graphsage_amd.train.Trainer(engine='autograd')")
         if not all(self.fused_layers):
             raise kernels._lib.GsageError(
                 "the training plan needs the fused layer kernel (feature and hidden widths in {32, 64, 128}, "

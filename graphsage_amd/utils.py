@@ -54,8 +54,6 @@ class Aggregator:
             raise ValueError("activation_function must be one of %s (the two the model uses)" % (_ACTIVATIONS,))
         self.activation = activation_function
         assert agg_option in ['mean', 'max'], "agg_option must be mean or max"
-        if agg_option != 'mean':
-            raise NotImplementedError("only the mean aggregator has a GPU kernel")
         self.agg_option = agg_option
         self.w_neigh = None
         self.w_self = None
@@ -104,6 +102,7 @@ class Aggregator:
         b, heads, fs = x_self.shape
         n, fn = x_neigh.shape[2], x_neigh.shape[3]
         m = b * heads
-        mean = _ag.GroupMean.apply(x_neigh.reshape(m, n, fn).contiguous(), m, n)
+        reduce = _ag.GroupMax if self.agg_option == 'max' else _ag.GroupMean
+        mean = reduce.apply(x_neigh.reshape(m, n, fn).contiguous(), m, n)
         out = self.project(x_self.reshape(m, fs).contiguous(), mean)
         return out.reshape(b, heads, self.output_dim)

@@ -138,6 +138,27 @@ int gs_gather_mean_bwd(const float *g_mean, const int32_t *child_ids, int64_t n_
                        float *g_feat, void *stream);
 
 /*
+ * The reference's other aggregation, agg_option='max' (utils.py:110-111:
+ * K.max(x_neigh, axis=2)): per parent and feature, the maximum over the n_child
+ * children.  Arguments as gs_gather_mean_fwd (child_ids NULL = dense groups); an
+ * id outside the table contributes a row of zeros.
+ */
+int gs_gather_max_fwd(const float *feat, int64_t n_rows, int F, int64_t id_offset,
+                      const int32_t *child_ids, int64_t n_parents, int n_child,
+                      float *out_max, void *stream);
+
+/*
+ * Gradient of the dense group max: x device float[n_parents*n_child, F] the
+ * children, out_max the forward result, g_max its gradient; g_x[child] =
+ * g_max[parent] / (number of children attaining the maximum) where the child
+ * attains it, else 0 -- TensorFlow's reduce_max rule (ties share evenly).
+ * Feature tables are inputs of the model, not variables (models.py:241), so the
+ * indexed form needs no gradient.
+ */
+int gs_group_max_bwd(const float *g_max, const float *x, const float *out_max, int64_t n_parents,
+                     int n_child, int F, float *g_x, void *stream);
+
+/*
  * out[m, :] = act(concat(x_self[m, :] @ W_self, x_mean[m, :] @ W_neigh) + bias)
  * The projection part of Aggregator.call (utils.py:109,114-119) with weights
  * shaped as Aggregator.build makes them (utils.py:72-89): W_self [Fs, H/2],

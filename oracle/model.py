@@ -34,9 +34,12 @@ def glorot_uniform(fan_in, fan_out, gen, dtype=torch.float32):
     return ((torch.rand(fan_in, fan_out, generator=gen, dtype=torch.float64) * 2 - 1) * limit).to(dtype)
 
 
-def aggregator(x_self, x_neigh, w_self, w_neigh, bias, act):
-    """x_self (B,h,Fs), x_neigh (B,h,n,Fn) -> (B,h,2*half)."""
-    neigh_agg = torch.matmul(x_neigh.mean(dim=2), w_neigh)
+def aggregator(x_self, x_neigh, w_self, w_neigh, bias, act, agg='mean'):
+    """x_self (B,h,Fs), x_neigh (B,h,n,Fn) -> (B,h,2*half).  ``agg`` 'mean' or
+    'max' (``utils.py:108-111``); ``amax`` shares its gradient evenly between
+    tied maxima, as TensorFlow's reduce_max does."""
+    reduced = x_neigh.amax(dim=2) if agg == 'max' else x_neigh.mean(dim=2)
+    neigh_agg = torch.matmul(reduced, w_neigh)
     self_agg = torch.matmul(x_self, w_self)
     out = torch.cat([self_agg, neigh_agg], dim=2)
     if bias is not None:
@@ -100,7 +103,7 @@ def init_weights(plan, gen, bias=True, dtype=torch.float32):
     return weights
 
 
-def forward(plan, weights, xin, normalize='l2', keep_layers=None):
+def forward(plan, weights, xin, normalize='l2', keep_layers=None, agg='mean'):
     h = list(xin)
     for layer in range(plan.n_layers):
         out = []
@@ -111,7 +114,7 @@ def forward(plan, weights, xin, normalize='l2', keep_layers=None):
             x_neigh = h[j].reshape(h[j].shape[0], heads, plan.n_samples[plan.depths[i]], n_dim)
             w = weights[(layer, node_type)]
             out.append(aggregator(h[i], x_neigh, w['w_self'], w['w_neigh'], w['bias'],
-                                  plan.activations[layer]))
+                                  plan.activations[layer], agg))
         h = out
         if keep_layers is not None:
             keep_layers.append(h)

@@ -289,6 +289,24 @@ def test_gather_rows_and_gather_mean(cuda, f, n_child):
     assert kernels.gather_rows(d_feat, d_ids[:0], off).shape == (0, f)
 
 
+@pytest.mark.parametrize('f,n_child', [(64, 10), (19, 25), (30, 9), (256, 1), (1, 70)])
+def test_gather_max_indexed_and_dense(cuda, f, n_child):
+    rng = np.random.default_rng(f * 31 + n_child)
+    n_rows, n_parents, off = 500, 77, 1000
+    feat = rng.standard_normal((n_rows, f)).astype(np.float32)
+    ids = rng.integers(0, n_rows, (n_parents, n_child)).astype(np.int32)
+    t = torch.from_numpy(feat).to(cuda)
+    got = kernels.gather_max(t, torch.from_numpy(ids + off).to(cuda).reshape(-1), n_parents, n_child, off)
+    np.testing.assert_array_equal(got.cpu().numpy(), feat[ids].max(axis=1))
+    dense = torch.from_numpy(feat[:(n_rows // n_child) * n_child]).to(cuda)
+    got = kernels.gather_max(dense, None, n_rows // n_child, n_child)
+    np.testing.assert_array_equal(got.cpu().numpy(), feat[:(n_rows // n_child) * n_child].reshape(-1, n_child, f).max(axis=1))
+    # all-negative rows: the identity of the reduction must not leak in (zeros would win)
+    neg = -np.abs(feat) - 1.0
+    got = kernels.gather_max(torch.from_numpy(neg).to(cuda), torch.from_numpy(ids).to(cuda).reshape(-1), n_parents, n_child)
+    np.testing.assert_array_equal(got.cpu().numpy(), neg[ids].max(axis=1))
+
+
 def test_gather_mean_many_children_and_unaligned_views(cuda):
     rng = np.random.default_rng(1)
     feat = rng.standard_normal((50, 64)).astype(np.float32)
@@ -404,13 +422,14 @@ def _oracle_model(model, plan):
 
 @pytest.mark.parametrize('ns,sizes,gname,b', [([8, 4], [32, 32], 'g_mid', 50), ([25, 10], [32, 32], 'g_mid', 9),
                                               ([4, 3, 2], [16, 8, 6], 'g_small', 7), ([3], [4], 'g_small', 5)])
-def test_model_embeddings_and_gradients_match_oracle(golden, cuda, ns, sizes, gname, b):
+@pytest.mark.parametrize('agg', ['mean', 'max'])
+def test_model_embeddings_and_gradients_match_oracle(golden, cuda, ns, sizes, gname, b, agg):
     arrays, _ = golden
     g = ga.Graph(*golden_graph_parts(arrays, gname))
     e = arrays[gname + '_edges']
     links = [(int(e[0, i]), int(e[1, i])) for i in range(b)]
     gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=4)
-    model = ga.GraphSAGE(sizes, gen, seed=9).build()
+    model = ga.GraphSAGE(sizes, gen, agg_option=agg, seed=9).build()
     for p in model.parameters():                      # biases away from zero so they matter
         if p.dim() == 1:
             p.data.uniform_(-0.1, 0.1)
@@ -419,7 +438,7 @@ def test_model_embeddings_and_gradients_match_oracle(golden, cuda, ns, sizes, gn
     plan = omodel.LayerPlan(sizes, ns, g.node_feature_sizes)
     weights = _oracle_model(model, plan)
     xin = [x.double() for x in map(torch.from_numpy, batch.numpy())]
-    want = omodel.forward(plan, weights, xin)
+    want = omodel.forward(plan, weights, xin, agg=agg)
 
     fused = model(batch)                              # ids -> gather-mean, deepest slots never materialised
     dense = model([batch[i] for i in range(len(batch))])
@@ -454,8 +473,20 @@ def test_aggregator_layer_call_convention(cuda):
     want = omodel.aggregator(x_self.double(), x_neigh.double(), agg.w_self.detach().cpu().double(),
                              agg.w_neigh.detach().cpu().double(), agg.bias.detach().cpu().double(), 'relu')
     close(out, want)
-    with pytest.raises(NotImplementedError):
-        ga.Aggregator(32, agg_option='max')
+    # the other aggregation of the reference
+    agg = ga.Aggregator(32, agg_option='max', seed=5)
+    x_neigh[0, 0, 3] = x_neigh[0, 0, 5]                   # tied maxima share the gradient
+    xs, xn = x_self.to(cuda).requires_grad_(True), x_neigh.to(cuda).requires_grad_(True)
+    out = agg([xs, xn])
+    os_, on_ = x_self.double().requires_grad_(True), x_neigh.double().requires_grad_(True)
+    want = omodel.aggregator(os_, on_, agg.w_self.detach().cpu().double(), agg.w_neigh.detach().cpu().double(),
+                             agg.bias.detach().cpu().double(), 'relu', agg='max')
+    close(out, want)
+    cot = torch.randn(6, 4, 32, generator=gen)
+    (out * cot.to(cuda)).sum().backward()
+    (want * cot.double()).sum().backward()
+    close(xn.grad, on_.grad, scale=float(on_.grad.abs().max()))
+    close(xs.grad, os_.grad, scale=float(os_.grad.abs().max()))
 
 
 # ------------------------------------------------- fused layer and engine ----
@@ -654,3 +685,33 @@ def test_walk_kernel_matches_layered_engine_and_oracle(cuda, ns, sizes, fu, fi):
     eng_w.err_flag.zero_()
     eng_w.forward(bad, walk_ids, rng_seed=1)
     assert eng_w.err_flag.tolist()[1] == 1
+
+
+def test_engine_runs_the_max_aggregator_through_the_general_kernels(cuda):
+    from graphsage_amd.engine import SageForwardEngine
+    rng = np.random.default_rng(11)
+    nu, ni, b, ns = 120, 30, 16, [6, 3]
+    u = np.concatenate([rng.integers(0, nu, 900), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 900), np.arange(nu) % ni]) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, 64)).astype(np.float32),
+             'item': rng.standard_normal((ni, 64)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=2)
+    model = ga.GraphSAGE([32, 32], gen, agg_option='max', seed=3).build()
+    links = [(int(e[0, i]), int(e[1, i])) for i in range(b)]
+    seeds = torch.tensor([l[0] for l in links] + [l[1] for l in links], dtype=torch.int32, device=cuda)
+    walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda)
+    eng = SageForwardEngine(g, model, b)
+    assert eng.agg_max and not eng.walk_kernel and not any(eng.fused_layers)
+    out = [x.clone() for x in eng.forward(seeds, walk_ids, rng_seed=8)]
+    hops = [h.cpu().numpy().astype(np.int64) for h in eng.hops]
+    xin = ogen.sample_features_fast({k: v.astype(np.float64) for k, v in feats.items()}, nu, links, hops)
+    plan = omodel.LayerPlan([32, 32], ns, g.node_feature_sizes)
+    want = omodel.forward(plan, _oracle_model(model, plan), [torch.from_numpy(x) for x in xin], agg='max')
+    for k in range(2):
+        close(out[k], want[k], scale=1.0)
+    from graphsage_amd.train_engine import SageTrainEngine
+    with pytest.raises(Exception):
+        SageTrainEngine(g, model, b)
