@@ -156,6 +156,159 @@ void rows_gemm_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     }
 }
 
+
+// ---- large-shape forward GEMM ----------------------------------------------
+//
+// For wide layers (K a multiple of 32, N a multiple of 128 per side) the product is
+// bound by the fp32 matrix pipe, not by HBM, and the 64x64 tile above spends most of
+// its time staging.  This variant: 128x128 block tile, 4 waves as 2x2, each wave a
+// 64x64 tile = 4x4 accumulators; K in steps of 32 through two LDS stages, the
+// next slice's global loads in flight while the current one is multiplied.
+// LDS holds fragments in lane order: the four k values a lane needs for four
+// consecutive MFMA steps are adjacent, so one ds_read_b128 per 16x16 tile feeds
+// four MFMAs and a wave's read is one contiguous 1 KB.  Within a 16-wide half of
+// the k slice, lane quarter q multiplies k = 4q + step at step 0..3 (any split of
+// k over (quarter, step) sums the same products).
+constexpr int GB_M = 128, GB_N = 128, GB_K = 32;
+constexpr int GB_TILE = GB_M * GB_K;                    // floats of one A (or B) stage
+constexpr size_t GB_LDS = size_t(4) * GB_TILE * sizeof(float);   // A and B, two stages each
+
+__global__ __launch_bounds__(kThreads, 2)
+void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
+    extern __shared__ __align__(16) float gb_smem[];
+    const int ncb0 = s0.N / GB_N;
+    const bool second = (int)blockIdx.y >= ncb0;
+#define GS_SEL(f) (second ? s1.f : s0.f)
+    const int col0 = ((int)blockIdx.y - (second ? ncb0 : 0)) * GB_N;
+    const float *__restrict__ A = GS_SEL(A);
+    const float *__restrict__ B = GS_SEL(B);
+    const float *__restrict__ bias = GS_SEL(bias);
+    float *__restrict__ outp = GS_SEL(out);
+    const int K = GS_SEL(K), lda = GS_SEL(lda), ldbk = GS_SEL(ldbk), ldo = GS_SEL(ldo);
+#undef GS_SEL
+    const int64_t row0 = (int64_t)blockIdx.x * GB_M;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wave_m = wave & 1, wave_n = wave >> 1;
+
+    // staging roles.  A: 8 lanes cover one row's 128-byte slice, 32 rows per pass, 4 passes.
+    const int a_kq = tid & 7;
+    const float *a_src[4];
+    int a_dst[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 32 + (tid >> 3);
+        int64_t grow = row0 + row;
+        if (grow > M - 1) grow = M - 1;                 // rows past the end repeat the last one; never stored
+        a_src[p] = A + grow * lda + a_kq * 4;
+        a_dst[p] = ((a_kq >> 2) * 8 + (row >> 4)) * 256 + ((a_kq & 3) * 16 + (row & 15)) * 4;
+    }
+    // B: a thread gathers four consecutive k of one column (4 scalar loads, coalesced over columns)
+    const float *b_src[4];
+    int b_dst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = j * 256 + tid;
+        const int col = idx & 127, kquad = idx >> 7;
+        b_src[j] = B + (int64_t)(kquad * 4) * ldbk + col0 + col;
+        b_dst[j] = ((kquad >> 2) * 8 + (col >> 4)) * 256 + ((kquad & 3) * 16 + (col & 15)) * 4;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the slice in flight lives in named registers (an indexed array here ends up in scratch)
+    float4 ar0, ar1, ar2, ar3, br0, br1, br2, br3;
+#define GB_LOAD_B(dst_, j_, k0_)                                                                   \
+    {                                                                                              \
+        const float *src = b_src[j_] + (int64_t)(k0_) * ldbk;                                      \
+        dst_ = make_float4(src[0], src[ldbk], src[2 * (int64_t)ldbk], src[3 * (int64_t)ldbk]);     \
+    }
+#define GB_LOAD_SLICE(k0_)                                                                         \
+    {                                                                                              \
+        const int k0 = (k0_);                                                                      \
+        ar0 = *reinterpret_cast<const float4 *>(a_src[0] + k0);                                    \
+        ar1 = *reinterpret_cast<const float4 *>(a_src[1] + k0);                                    \
+        ar2 = *reinterpret_cast<const float4 *>(a_src[2] + k0);                                    \
+        ar3 = *reinterpret_cast<const float4 *>(a_src[3] + k0);                                    \
+        GB_LOAD_B(br0, 0, k0) GB_LOAD_B(br1, 1, k0) GB_LOAD_B(br2, 2, k0) GB_LOAD_B(br3, 3, k0)    \
+    }
+#define GB_STORE_SLICE(stage_)                                                                     \
+    {                                                                                              \
+        float *As_w = gb_smem + (stage_) * 2 * GB_TILE, *Bs_w = As_w + GB_TILE;                    \
+        *reinterpret_cast<float4 *>(As_w + a_dst[0]) = ar0;                                        \
+        *reinterpret_cast<float4 *>(As_w + a_dst[1]) = ar1;                                        \
+        *reinterpret_cast<float4 *>(As_w + a_dst[2]) = ar2;                                        \
+        *reinterpret_cast<float4 *>(As_w + a_dst[3]) = ar3;                                        \
+        *reinterpret_cast<float4 *>(Bs_w + b_dst[0]) = br0;                                        \
+        *reinterpret_cast<float4 *>(Bs_w + b_dst[1]) = br1;                                        \
+        *reinterpret_cast<float4 *>(Bs_w + b_dst[2]) = br2;                                        \
+        *reinterpret_cast<float4 *>(Bs_w + b_dst[3]) = br3;                                        \
+    }
+
+    GB_LOAD_SLICE(0);
+    GB_STORE_SLICE(0);
+    __syncthreads();
+    const int n_slices = K / GB_K;
+    for (int kt = 0; kt < n_slices; ++kt) {
+        const int stage = kt & 1;
+        // next slice in flight during the multiply; the last iteration re-reads its own slice (unused)
+        GB_LOAD_SLICE(min(kt + 1, n_slices - 1) * GB_K);
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the multiply (the scheduler would sink them)
+        const float *As = gb_smem + stage * 2 * GB_TILE, *Bs = As + GB_TILE;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const f32x4 *>(As + (half * 8 + wave_m * 4 + i) * 256 + lane * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = *reinterpret_cast<const f32x4 *>(Bs + (half * 8 + wave_n * 4 + j) * 256 + lane * 4);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][st], b[j][st], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        GB_STORE_SLICE(stage ^ 1);          // that stage was last read before the previous barrier
+        __syncthreads();
+    }
+#undef GB_LOAD_SLICE
+#undef GB_LOAD_B
+#undef GB_STORE_SLICE
+
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = col0 + wave_n * 64 + j * 16 + r;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t grow = row0 + wave_m * 64 + i * 16 + q * 4 + e;
+                if (grow < M) {
+                    float v = acc[i][j][e] + bv;
+                    if (act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                    outp[grow * ldo + col] = v;
+                }
+            }
+        }
+    }
+}
+
+inline bool big_gemm_applies(const GemmSide &s) {
+    return s.vec && s.K % GB_K == 0 && s.N % GB_N == 0 && s.ldbn == 1 && !s.mask &&
+           (reinterpret_cast<uintptr_t>(s.A) & 15) == 0 && s.lda % 4 == 0;
+}
+
 // ---- weight / bias gradient ------------------------------------------------
 
 struct WgradSide {
@@ -389,6 +542,16 @@ extern "C" int gs_sage_project_fwd(const float *x_self, int Fs, const float *x_m
     const int64_t bx = (M + BM - 1) / BM;
     const int by = s0.ncb + s1.ncb;
     if (bx > 0x7FFFFFFFLL || by > 65535) return gs::fail(GS_ELIMIT, "gs_sage_project_fwd: grid %lld x %d too large", (long long)bx, by);
+    if (big_gemm_applies(s0) && big_gemm_applies(s1) && M >= 4 * GB_M) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rows_gemm_big_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS);
+        if (attr != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage_project_fwd: LDS attribute: %s", hipGetErrorString(attr));
+        const int64_t gx = (M + GB_M - 1) / GB_M;
+        const int gy = 2 * (Hh / GB_N);
+        hipLaunchKernelGGL(rows_gemm_big_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), GB_LDS,
+                           (hipStream_t)stream, s0, s1, M, act);
+        return gs::check_launch("gs_sage_project_fwd");
+    }
     hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)bx, (unsigned)by), dim3(kThreads), 0, (hipStream_t)stream,
                        s0, s1, M, act);
     return gs::check_launch("gs_sage_project_fwd");
