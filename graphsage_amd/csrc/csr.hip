@@ -3,11 +3,14 @@
 //
 // The reference makes one np.where scan of the whole edge array per node
 // (bipartite_graph.py:53-60), from an edge array that already holds both
-// directions (train_movielens.py:130-132).  Here: count degrees, scan them into
-// row starts, then a stable counting sort by source node made of chunked radix
-// sorts (hipCUB) whose runs are appended to each node's row through a per-node
-// cursor.  No atomics decide positions, so the result is the same on every run
-// and on every GPU.
+// directions (train_movielens.py:130-132).  Here the edge array is taken in
+// chunks; a chunk's sources are radix-sorted (hipCUB), which turns every node's
+// entries in the chunk into one run.  Pass 1 adds the run lengths into the
+// degrees (a popular item would serialise an atomic histogram: one address, tens
+// of millions of increments), a scan turns degrees into row starts, pass 2 sorts
+// (source, destination) pairs stably and appends each run to its node's row
+// through a per-node cursor.  No atomics anywhere, so the result is the same on
+// every run and on every GPU.
 #include "gs_common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -33,6 +36,11 @@ static int make_plan(int64_t n_half, int64_t n_nodes, int64_t sort_chunk, CsrPla
                                                       (const int32_t *)nullptr, (int32_t *)nullptr, p->chunk, 0, 32,
                                                       (hipStream_t)0);
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_csr_build: radix sort size query: %s", hipGetErrorString(e));
+    size_t keys_bytes = 0;
+    e = hipcub::DeviceRadixSort::SortKeys(nullptr, keys_bytes, (const int32_t *)nullptr, (int32_t *)nullptr, p->chunk, 0,
+                                          32, (hipStream_t)0);
+    if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_csr_build: radix sort size query: %s", hipGetErrorString(e));
+    if (keys_bytes > sort_bytes) sort_bytes = keys_bytes;
     e = hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, (int64_t *)nullptr, (int64_t *)nullptr, int(n_nodes),
                                          (hipStream_t)0);
     if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_csr_build: scan size query: %s", hipGetErrorString(e));
@@ -47,23 +55,29 @@ static int make_plan(int64_t n_half, int64_t n_nodes, int64_t sort_chunk, CsrPla
     return GS_OK;
 }
 
-// deg[src] += 1 for every entry; flags ids outside [0, n_nodes).
-__global__ __launch_bounds__(kCsrBlock) void csr_count_kernel(const int32_t *__restrict__ a,
+// Flags ids outside [0, n_nodes).
+__global__ __launch_bounds__(kCsrBlock) void csr_check_kernel(const int32_t *__restrict__ a,
                                                               const int32_t *__restrict__ b, int64_t n_pairs,
-                                                              int symmetric, int64_t n_nodes,
-                                                              unsigned long long *__restrict__ deg,
-                                                              int32_t *__restrict__ err_flag) {
+                                                              int64_t n_nodes, int32_t *__restrict__ err_flag) {
     const int64_t stride = int64_t(gridDim.x) * kCsrBlock;
+    bool bad = false;
     for (int64_t i = int64_t(blockIdx.x) * kCsrBlock + threadIdx.x; i < n_pairs; i += stride) {
         const int32_t s = a[i], d = b[i];
-        const bool ok = s >= 0 && s < n_nodes && d >= 0 && d < n_nodes;
-        if (!ok) {
-            atomicMax(err_flag, 1);
-            continue;
-        }
-        atomicAdd(deg + s, 1ull);
-        if (symmetric) atomicAdd(deg + d, 1ull);
+        bad |= !(s >= 0 && s < n_nodes && d >= 0 && d < n_nodes);
     }
+    if (bad) atomicMax(err_flag, 1);
+}
+
+// Pass 1, after csr_run_starts_kernel on a chunk of sorted sources: the last entry of every
+// run adds the run length to its node's degree (one run per node per chunk, chunks in stream order).
+__global__ __launch_bounds__(kCsrBlock) void csr_add_runs_kernel(const int32_t *__restrict__ keys, int64_t n,
+                                                                 const int32_t *__restrict__ lstart,
+                                                                 int64_t *__restrict__ deg,
+                                                                 const int32_t *__restrict__ err_flag) {
+    const int64_t j = int64_t(blockIdx.x) * kCsrBlock + threadIdx.x;
+    if (j >= n || *err_flag) return;
+    const int32_t k = keys[j];
+    if (j == n - 1 || keys[j + 1] != k) deg[k] += (j - lstart[k]) + 1;
 }
 
 // keys: one sorted chunk.  The first entry of every run records where the run starts.
@@ -139,13 +153,32 @@ extern "C" int gs_csr_build(const int32_t *a, const int32_t *b, int64_t n_pairs,
     int32_t *vals = reinterpret_cast<int32_t *>(ws + p.off_vals);
     void *sort_ws = ws + p.off_sort;
 
-    // degrees into indptr[1..], then an inclusive scan in place turns them into row ends = next row starts
+    int end_bit = 1;
+    while (end_bit < 31 && (int64_t(1) << end_bit) < n_nodes) ++end_bit;
+    const int n_halves = symmetric ? 2 : 1;
+
     {
         const int64_t want = (n_pairs + kCsrBlock - 1) / kCsrBlock;
         const int grid = int(want < 256 * 32 ? want : 256 * 32);
-        csr_count_kernel<<<grid, kCsrBlock, 0, stream>>>(a, b, n_pairs, symmetric, n_nodes,
-                                                          reinterpret_cast<unsigned long long *>(indptr + 1), err_flag);
-        if (int rc = check_launch("gs_csr_build: count")) return rc;
+        csr_check_kernel<<<grid, kCsrBlock, 0, stream>>>(a, b, n_pairs, n_nodes, err_flag);
+        if (int rc = check_launch("gs_csr_build: check")) return rc;
+    }
+    // pass 1: degrees into indptr[1..] from the runs of each sorted chunk of sources
+    for (int half = 0; half < n_halves; ++half) {
+        const int32_t *src = half ? b : a;
+        for (int64_t c0 = 0; c0 < n_pairs; c0 += p.chunk) {
+            const int64_t n = n_pairs - c0 < p.chunk ? n_pairs - c0 : p.chunk;
+            size_t sb = p.sort_bytes;
+            e = hipcub::DeviceRadixSort::SortKeys(sort_ws, sb, src + c0, keys, n, 0, end_bit, stream);
+            if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_csr_build: radix sort: %s", hipGetErrorString(e));
+            const int grid = int((n + kCsrBlock - 1) / kCsrBlock);
+            csr_run_starts_kernel<<<grid, kCsrBlock, 0, stream>>>(keys, n, lstart, err_flag);
+            csr_add_runs_kernel<<<grid, kCsrBlock, 0, stream>>>(keys, n, lstart, indptr + 1, err_flag);
+            if (int rc = check_launch("gs_csr_build: count")) return rc;
+        }
+    }
+    // an inclusive scan in place turns degrees into row ends = next row starts
+    {
         size_t scan_bytes = p.sort_bytes;
         e = hipcub::DeviceScan::InclusiveSum(sort_ws, scan_bytes, indptr + 1, indptr + 1, int(n_nodes), stream);
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_csr_build: scan: %s", hipGetErrorString(e));
@@ -153,11 +186,8 @@ extern "C" int gs_csr_build(const int32_t *a, const int32_t *b, int64_t n_pairs,
         if (e != hipSuccess) return fail(GS_ELAUNCH, "gs_csr_build: cursor copy: %s", hipGetErrorString(e));
     }
 
-    int end_bit = 1;
-    while (end_bit < 31 && (int64_t(1) << end_bit) < n_nodes) ++end_bit;
-
-    // entries in column order: the pairs as given, then (for symmetric input) the flipped pairs
-    for (int half = 0; half < (symmetric ? 2 : 1); ++half) {
+    // pass 2, entries in column order: the pairs as given, then (for symmetric input) the flipped pairs
+    for (int half = 0; half < n_halves; ++half) {
         const int32_t *src = half ? b : a, *dst = half ? a : b;
         for (int64_t c0 = 0; c0 < n_pairs; c0 += p.chunk) {
             const int64_t n = n_pairs - c0 < p.chunk ? n_pairs - c0 : p.chunk;

@@ -462,6 +462,157 @@ void wgrad_reduce_kernel(ReduceSide s0, ReduceSide s1, int n_chunks, int N) {
     }
 }
 
+
+// ---- weight / bias gradient for narrow outputs, operands straight from global memory --------
+//
+// dW[k, n] = sum_m X[m, k] * G[m, n] with K in {32, 64, 128} per half and a half-width of 16
+// or 32 is bound by reading X and G once, not by the matrix pipe.  One MFMA step covers four
+// rows of M: lane (r, q) holds X[m0 + q][V*r .. V*r + V-1] (V = K/16 consecutive floats, one
+// vector load; a wave reads whole rows, contiguous) and G[m0 + q][r].  Accumulator t then holds
+// the weight rows k = V*i + t: V accumulators cover all K.  Both halves (self, neighbor) run in
+// the same wave, so the gradient row is read once.  A block's four waves take consecutive row
+// ranges and add their accumulators through LDS in wave order; wgrad_reduce_kernel adds the
+// blocks' slabs in block order -- bitwise reproducible like the tiled kernel.
+template <int V> struct XVec;
+template <> struct XVec<2> { float v[2]; __device__ __forceinline__ void load(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; } };
+template <> struct XVec<4> { float v[4]; __device__ __forceinline__ void load(const float *p) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; } };
+template <> struct XVec<8> { float v[8]; __device__ __forceinline__ void load(const float *p) {
+    const float4 t = *reinterpret_cast<const float4 *>(p), u = *reinterpret_cast<const float4 *>(p + 4);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; } };
+
+constexpr int WD_UNROLL = 4;            // MFMA steps (of four rows) whose loads are in flight together
+
+template <int KS, int KN, int NT>
+__global__ __launch_bounds__(kThreads)
+void wgrad_direct_kernel(const float *__restrict__ Xs, const float *__restrict__ Xn,
+                         const float *__restrict__ G, const float *__restrict__ Mk, int64_t M,
+                         int64_t rows_per_block, float *__restrict__ slab_s, float *__restrict__ slab_n) {
+    constexpr int VS = KS / 16, VN = KN / 16, HH = NT * 16, H = 2 * HH;
+    constexpr int kSlabS = (KS + 1) * HH, kSlabN = (KN + 1) * HH;
+    __shared__ float red[kSlabS + kSlabN];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t b_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t b_end = min(M, b_begin + rows_per_block);
+    // consecutive quarter ranges (multiples of 4 rows) for the four waves
+    const int64_t per_wave = ((b_end - b_begin + 15) / 16) * 4;
+    const int64_t w_begin = min(b_end, b_begin + wave * per_wave), w_end = min(b_end, w_begin + per_wave);
+
+    f32x4 acc_s[VS][NT], acc_n[VN][NT];
+    float bias_s[NT], bias_n[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bias_s[nt] = bias_n[nt] = 0.f;
+#pragma unroll
+        for (int t = 0; t < VS; ++t) acc_s[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < VN; ++t) acc_n[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int64_t m0 = w_begin; m0 < w_end; m0 += 4 * WD_UNROLL) {
+        XVec<VS> xs[WD_UNROLL];
+        XVec<VN> xn[WD_UNROLL];
+        float gs_[WD_UNROLL][NT], gn_[WD_UNROLL][NT];
+#pragma unroll
+        for (int u = 0; u < WD_UNROLL; ++u) {
+            const int64_t m = m0 + 4 * u + q;
+            const bool live = m < w_end;
+            const int64_t mc = live ? m : w_end - 1;            // a row past the range is read in place, weight 0
+            xs[u].load(Xs + mc * KS + VS * r);
+            xn[u].load(Xn + mc * KN + VN * r);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float a = G[mc * H + nt * 16 + r], b = G[mc * H + HH + nt * 16 + r];
+                if (Mk) {
+                    if (!(Mk[mc * H + nt * 16 + r] > 0.f)) a = 0.f;
+                    if (!(Mk[mc * H + HH + nt * 16 + r] > 0.f)) b = 0.f;
+                }
+                gs_[u][nt] = live ? a : 0.f;
+                gn_[u][nt] = live ? b : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WD_UNROLL; ++u) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int t = 0; t < VS; ++t)
+                    acc_s[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[u].v[t], gs_[u][nt], acc_s[t][nt], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < VN; ++t)
+                    acc_n[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[u].v[t], gn_[u][nt], acc_n[t][nt], 0, 0, 0);
+                bias_s[nt] += gs_[u][nt];
+                bias_n[nt] += gn_[u][nt];
+            }
+        }
+    }
+    // column sums: the four row classes (q) of a column, added in q order
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bias_s[nt] += __shfl_xor(bias_s[nt], 16, 64);
+        bias_s[nt] += __shfl_xor(bias_s[nt], 32, 64);
+        bias_n[nt] += __shfl_xor(bias_n[nt], 16, 64);
+        bias_n[nt] += __shfl_xor(bias_n[nt], 32, 64);
+    }
+    // the block's sum in LDS, in slab layout ([k][n], then the bias row), waves added in order
+#pragma unroll 1
+    for (int w = 0; w < kThreads / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int t = 0; t < VS; ++t) {
+                        float *dst = red + (VS * (4 * q + e) + t) * HH + nt * 16 + r;
+                        *dst = w ? *dst + acc_s[t][nt][e] : acc_s[t][nt][e];
+                    }
+#pragma unroll
+                    for (int t = 0; t < VN; ++t) {
+                        float *dst = red + kSlabS + (VN * (4 * q + e) + t) * HH + nt * 16 + r;
+                        *dst = w ? *dst + acc_n[t][nt][e] : acc_n[t][nt][e];
+                    }
+                }
+                if (q == 0) {
+                    float *ds = red + KS * HH + nt * 16 + r, *dn = red + kSlabS + KN * HH + nt * 16 + r;
+                    *ds = w ? *ds + bias_s[nt] : bias_s[nt];
+                    *dn = w ? *dn + bias_n[nt] : bias_n[nt];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *out_s = slab_s + (int64_t)blockIdx.x * kSlabS, *out_n = slab_n + (int64_t)blockIdx.x * kSlabN;
+    for (int i = tid; i < kSlabS; i += kThreads) out_s[i] = red[i];
+    for (int i = tid; i < kSlabN; i += kThreads) out_n[i] = red[kSlabS + i];
+}
+
+#define GS_WGRAD_DIRECT_CASES(X) \
+    X(32, 32, 1) X(32, 64, 1) X(64, 32, 1) X(64, 64, 1) X(64, 128, 1) X(128, 64, 1) X(128, 128, 1) X(32, 128, 1) X(128, 32, 1) \
+    X(32, 32, 2) X(32, 64, 2) X(64, 32, 2) X(64, 64, 2) X(64, 128, 2) X(128, 64, 2) X(128, 128, 2) X(32, 128, 2) X(128, 32, 2)
+
+// rows per block for the direct kernel: at most 512 blocks, at least 128 rows each (so the
+// slab count never exceeds the chunk count the workspace was sized for)
+inline int64_t wgrad_direct_rows(int64_t M) {
+    int64_t rpb = (M + 511) / 512;
+    rpb = ((rpb + 15) / 16) * 16;
+    return rpb < 128 ? 128 : rpb;
+}
+
+inline bool launch_wgrad_direct(int Fs, int Fn, int Hh, const float *xs, const float *xn, const float *g,
+                                const float *mask, int64_t M, int64_t rpb, int64_t nblocks, float *slab_s,
+                                float *slab_n, hipStream_t s) {
+#define GS_CASE(KS_, KN_, NT_)                                                                              \
+    if (Fs == KS_ && Fn == KN_ && Hh == NT_ * 16) {                                                         \
+        hipLaunchKernelGGL((wgrad_direct_kernel<KS_, KN_, NT_>), dim3((unsigned)nblocks), dim3(kThreads), 0, s, \
+                           xs, xn, g, mask, M, rpb, slab_s, slab_n);                                        \
+        return true;                                                                                        \
+    }
+    GS_WGRAD_DIRECT_CASES(GS_CASE)
+#undef GS_CASE
+    return false;
+}
+
 // ---- l2 normalisation ---------------------------------------------------------
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -587,7 +738,20 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
             return gs::fail(GS_EINVAL, "gs_sage_project_bwd: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
         float *slab0 = static_cast<float *>(workspace);
         float *slab1 = slab0 + (size_t)nc * (Fs + 1) * Hh;
-        if (M > 0) {
+        bool direct = false;
+        if (M > 0 && aligned16(x_self) && aligned16(x_mean) && aligned16(g_out) && (!mask || aligned16(mask))) {
+            const int64_t rpb = wgrad_direct_rows(M);
+            const int64_t nblocks = (M + rpb - 1) / rpb;          // <= nc: the slabs fit the workspace
+            slab1 = slab0 + (size_t)nblocks * (Fs + 1) * Hh;
+            direct = launch_wgrad_direct(Fs, Fn, Hh, x_self, x_mean, g_out, mask, M, rpb, nblocks, slab0, slab1, s);
+            if (direct) {
+                if (int rc = gs::check_launch("gs_sage_project_bwd (wgrad)")) return rc;
+                nc = nblocks;
+            } else {
+                slab1 = slab0 + (size_t)nc * (Fs + 1) * Hh;
+            }
+        }
+        if (M > 0 && !direct) {
             WgradSide a{}, b{};
             a.X = x_self; a.G = g_out; a.mask = mask; a.slab = slab0; a.K = Fs; a.N = Hh; a.ldg = H;
             a.nkb = (Fs + 63) / 64; a.ncb = (Hh + 63) / 64;

@@ -16,7 +16,8 @@ from collections import defaultdict
 src, name = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ours = ('sage2_kernel', 'sage_fused_kernel', 'sample_kernel', 'gather_mean_kernel', 'gather_rows_kernel', 'rows_gemm_kernel',
-        'wgrad_kernel', 'wgrad_reduce_kernel', 'l2norm')
+        'rows_gemm_big_kernel', 'wgrad_kernel', 'wgrad_reduce_kernel', 'l2norm', 'link_head', 'adam_kernel', 'csr_',
+        'group_max_bwd_kernel', 'head_')
 
 
 def short(n):
@@ -31,7 +32,7 @@ lines = ['# rocprofv3 summary: %s' % name, '']
 bl = os.path.join(src, 'bench_line.json')
 if os.path.exists(bl):
     lines += ['bench line of the traced run:', '', '```', open(bl).read().strip(), '```', '']
-stats = glob.glob(os.path.join(src, 'trace', '*', '*kernel_stats.csv'))
+stats = sorted(glob.glob(os.path.join(src, 'trace', '*', '*kernel_stats.csv')), key=os.path.getmtime, reverse=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     lines += ['## kernel time (rocprofv3 --kernel-trace --stats), kernels of libgsage.so', '',
@@ -45,7 +46,7 @@ if stats:
 
 traffic = {}
 for kind, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
-    files = glob.glob(os.path.join(src, kind, '*', '*counter_collection.csv'))
+    files = sorted(glob.glob(os.path.join(src, kind, '*', '*counter_collection.csv')), key=os.path.getmtime, reverse=True)
     if not files:
         continue
     acc = defaultdict(list)
