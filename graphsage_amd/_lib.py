@@ -59,12 +59,17 @@ class SageWeights(_c.Structure):
     _fields_ = [('w_self', _vp), ('w_neigh', _vp), ('bias', _vp)]
 
 
+class Sage2Saved(_c.Structure):
+    """gs_sage2_saved of include/gsage.h."""
+    _fields_ = [('x_self', _vp * 2), ('x_mean', _vp * 2), ('h1', _vp * 2), ('x_mean1', _vp * 2), ('z', _vp * 2)]
+
+
 SIGNATURES['gs_sage2_supported'] = (_i32, [_i32] * 6)
 SIGNATURES['gs_sage2_forward'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
                                          _u64, _u64, _vp, _vp,
                                          _c.POINTER(SageWeights), _c.POINTER(SageWeights),
                                          _c.POINTER(SageWeights), _c.POINTER(SageWeights),
-                                         _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp])
+                                         _i32, _i32, _i32, _vp, _vp, _vp, _c.POINTER(Sage2Saved), _vp, _vp])
 
 _f32 = _c.c_float
 SIGNATURES['gs_link_head_workspace'] = (_sz, [_i64, _i32])

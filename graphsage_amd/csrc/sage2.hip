@@ -50,6 +50,11 @@ struct Sage2Args {
     int normalize;
     float *emb; int32_t *out_hop1, *out_hop2; int32_t *err;
     int ids_per_wave, h1_rows;
+    // training: what the backward pass reads, by node type (NULL pointers when SAVE is off).
+    // Tables of n_pairs * (1 + n0) rows: row p is the root of pair p of that type, row
+    // n_pairs + p*n0 + j hop-1 head j of the walk rooted at the other type's root of pair p.
+    float *sv_x_self[2], *sv_x_mean[2], *sv_h1[2];
+    float *sv_x_mean1[2], *sv_z[2];                   // n_pairs rows: layer-1 neighbor mean, pre-norm output
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -135,7 +140,7 @@ struct Sage2Shape {
 };
 
 // One walk.  FT / FO: feature widths of the root's type and of the other type.
-template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF>
+template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, bool SAVE>
 __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int side, int lane,
                                           int32_t root, int64_t ra, int64_t rb,
                                           int32_t next_root, int64_t &next_ra, int64_t &next_rb,
@@ -218,6 +223,8 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     }
 
     // ---- layer 0, hop-1 heads (type O; children type T) ---------------------------------
+    const long long pair = w - (side ? a.n_pairs : 0);
+    const long long sv_h1row = a.n_pairs + pair * n0;       // first row of this walk's hop-1 heads in the type-O tables
     constexpr int RP_O = 64 / FOV, NPASS_O = 16 / RP_O;     // own rows per load instruction / passes per tile
     constexpr int GN_T = 64 / FTV;                           // lane groups summing children rows
     float4 rootsum = make_float4(0.f, 0.f, 0.f, 0.f);        // partial sum of the hop-1 rows, for the root's mean
@@ -268,9 +275,12 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
 #pragma unroll
                 for (int hd = 0; hd < kHeads; ++hd) {
                     const int pp = pp0 + hd * GN_T;
-                    if (pp < 16)
-                        *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) =
-                            make_float4(acc[hd].x / denom, acc[hd].y / denom, acc[hd].z / denom, acc[hd].w / denom);
+                    if (pp < 16) {
+                        const float4 mean = make_float4(acc[hd].x / denom, acc[hd].y / denom, acc[hd].z / denom, acc[hd].w / denom);
+                        *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) = mean;
+                        if (SAVE && pp < np)
+                            *reinterpret_cast<float4 *>(a.sv_x_mean[1 - side] + (size_t)(sv_h1row + j0 + pp) * FT + 4 * c) = mean;
+                    }
                 }
             }
         }
@@ -284,6 +294,8 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         for (int pass = 0; pass < NPASS_O; ++pass) {
             const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
             *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = own[pass];
+            if (SAVE && rr < np)
+                *reinterpret_cast<float4 *>(a.sv_x_self[1 - side] + (size_t)(sv_h1row + j0 + rr) * FO + 4 * c) = own[pass];
             rootsum.x += own[pass].x; rootsum.y += own[pass].y; rootsum.z += own[pass].z; rootsum.w += own[pass].w;
         }
         wave_lds_fence();
@@ -316,8 +328,12 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         {
             own_root = tabT.load(root >= 0 && lane < FTV, (unsigned)(root - offT), (unsigned)(lane % FTV) * 16u, FT * 4);
         }
-        if (lane < FOV)
-            *reinterpret_cast<float4 *>(A + 4 * lane) = make_float4(rootsum.x / d0, rootsum.y / d0, rootsum.z / d0, rootsum.w / d0);
+        if (lane < FOV) {
+            const float4 mean = make_float4(rootsum.x / d0, rootsum.y / d0, rootsum.z / d0, rootsum.w / d0);
+            *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
+            if (SAVE) *reinterpret_cast<float4 *>(a.sv_x_mean[side] + (size_t)pair * FO + 4 * lane) = mean;
+        }
+        if (SAVE && lane < FTV) *reinterpret_cast<float4 *>(a.sv_x_self[side] + (size_t)pair * FT + 4 * lane) = own_root;
         wave_lds_fence();
         f32x4 acc_s[NT1], acc_n[NT1];
 #pragma unroll
@@ -352,7 +368,19 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             s.z += __shfl_xor(s.z, m, 64); s.w += __shfl_xor(s.w, m, 64);
         }
         const float d0 = (float)n0;
-        if (lane < H1V) *reinterpret_cast<float4 *>(A + 4 * lane) = make_float4(s.x / d0, s.y / d0, s.z / d0, s.w / d0);
+        if (lane < H1V) {
+            const float4 mean = make_float4(s.x / d0, s.y / d0, s.z / d0, s.w / d0);
+            *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
+            if (SAVE) *reinterpret_cast<float4 *>(a.sv_x_mean1[side] + (size_t)pair * H1 + 4 * lane) = mean;
+        }
+        if (SAVE) {
+            // layer-0 activations: the root's row, then the hop-1 heads' rows as one contiguous block (LDH == H1)
+            if (lane < H1V)
+                *reinterpret_cast<float4 *>(a.sv_h1[side] + (size_t)pair * H1 + 4 * lane) = *reinterpret_cast<const float4 *>(H1t + 4 * lane);
+            float *dst = a.sv_h1[1 - side] + (size_t)sv_h1row * H1;
+            for (int i = lane; i < n0 * H1V; i += 64)
+                *reinterpret_cast<float4 *>(dst + 4 * i) = *reinterpret_cast<const float4 *>(H1t + LDH + 4 * i);
+        }
         wave_lds_fence();
         f32x4 acc_s[NT2], acc_n[NT2];
 #pragma unroll
@@ -369,6 +397,11 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             o[0][ct] = acc_s[ct][0] + b1_T[ct * 16 + r];
             o[1][ct] = acc_n[ct][0] + b1_T[HH2 + ct * 16 + r];
             ss += o[0][ct] * o[0][ct] + o[1][ct] * o[1][ct];
+        }
+        if (SAVE && q == 0) {
+            float *dz = a.sv_z[side] + (size_t)pair * H2;
+#pragma unroll
+            for (int ct = 0; ct < NT2; ++ct) { dz[ct * 16 + r] = o[0][ct]; dz[HH2 + ct * 16 + r] = o[1][ct]; }
         }
         if (a.normalize) {
 #pragma unroll
@@ -388,7 +421,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     }
 }
 
-template <int FU, int FI, int HH1, int HH2, bool BUF>
+template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE>
 __global__ __launch_bounds__(kWaves * 64)
 void sage2_kernel(const Sage2Args a) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
@@ -444,23 +477,23 @@ void sage2_kernel(const Sage2Args a) {
         const int32_t next_root = pn < a.n_pairs ? load_root(pn) : -1;
         int64_t nra = 0, nrb = 0;
         if (side == 0)
-            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF>(a, p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF, SAVE>(a, p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_u, w0n_u, w0s_i, w0n_i, w1s, w1n, bias, bias + H1, bias + 2 * H1);
         else
-            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF>(a, a.n_pairs + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF, SAVE>(a, a.n_pairs + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_i, w0n_i, w0s_u, w0n_u, w1s, w1n, bias + H1, bias, bias + 2 * H1);
         root = next_root; ra = nra; rb = nrb;
     }
 }
 
-template <int FU, int FI, int HH1, int HH2, bool BUF>
+template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE>
 int launch_one(const Sage2Args &a, hipStream_t stream) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     int waves = kWaves;                                  // as many waves per CU as the LDS budget admits
     while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves) > kLdsMax) waves -= 2;
     const size_t lds = S::lds_bytes(a.n0, a.n1, waves);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
-    auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF>;
+    auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF, SAVE>;
     static thread_local const void *configured = nullptr;
     if (lds > 64 * 1024 && configured != (const void *)kern) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
@@ -477,8 +510,9 @@ template <int FU, int FI, int HH1, int HH2>
 int launch(const Sage2Args &a, hipStream_t stream) {
     // buffer addressing needs both tables inside a 4 GiB window
     const long long lim = 0xFFFFFFF0LL;
-    if (a.n_rows[0] * FU * 4 < lim && a.n_rows[1] * FI * 4 < lim) return launch_one<FU, FI, HH1, HH2, true>(a, stream);
-    return launch_one<FU, FI, HH1, HH2, false>(a, stream);
+    const bool buf = a.n_rows[0] * FU * 4 < lim && a.n_rows[1] * FI * 4 < lim;
+    if (a.sv_z[0]) return buf ? launch_one<FU, FI, HH1, HH2, true, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, true>(a, stream);
+    return buf ? launch_one<FU, FI, HH1, HH2, true, false>(a, stream) : launch_one<FU, FI, HH1, HH2, false, false>(a, stream);
 }
 
 // LDS of the smallest block this kernel runs with (4 waves)
@@ -518,7 +552,7 @@ extern "C" int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, i
                                 const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
                                 int H1, int H2, int normalize,
                                 float *emb, int32_t *out_hop1, int32_t *out_hop2,
-                                int32_t *err_flag, void *stream) {
+                                const gs_sage2_saved *saved, int32_t *err_flag, void *stream) {
     if (n_pairs < 0) return gs::fail(GS_EINVAL, "gs_sage2_forward: n_pairs=%lld", (long long)n_pairs);
     if (n_pairs == 0) return GS_OK;
     if (!indptr || !indices || !feat_user || !feat_item || !seeds || !emb || !err_flag ||
@@ -548,6 +582,17 @@ extern "C" int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, i
     a.normalize = normalize; a.emb = emb; a.out_hop1 = out_hop1; a.out_hop2 = out_hop2; a.err = err_flag;
     a.ids_per_wave = ((n0 + n0 * n1) + 3) & ~3;
     a.h1_rows = 1 + n0;
+    if (saved) {
+        for (int t = 0; t < 2; ++t) {
+            if (!saved->x_self[t] || !saved->x_mean[t] || !saved->h1[t] || !saved->x_mean1[t] || !saved->z[t])
+                return gs::fail(GS_EINVAL, "gs_sage2_forward: saved-activation set has a null pointer");
+            if (!aligned16(saved->x_self[t]) || !aligned16(saved->x_mean[t]) || !aligned16(saved->h1[t]) ||
+                !aligned16(saved->x_mean1[t]))
+                return gs::fail(GS_EINVAL, "gs_sage2_forward: saved-activation buffers must be 16-byte aligned");
+            a.sv_x_self[t] = saved->x_self[t]; a.sv_x_mean[t] = saved->x_mean[t]; a.sv_h1[t] = saved->h1[t];
+            a.sv_x_mean1[t] = saved->x_mean1[t]; a.sv_z[t] = saved->z[t];
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     const int hh1 = H1 / 2, hh2 = H2 / 2;
 #define GS_X(fu, fi, a1, a2) if (Fu == fu && Fi == fi && hh1 == a1 && hh2 == a2) return launch<fu, fi, a1, a2>(a, s);

@@ -384,7 +384,9 @@ class Sage2Call:
     """
 
     def __init__(self, indptr, indices, feat_user, feat_item, fanouts, weights, normalize, n_pairs,
-                 emb=None, keep_ids=False):
+                 emb=None, keep_ids=False, saved=None):
+        """``saved`` (training): {'x_self', 'x_mean', 'h1', 'x_mean1', 'z'} -> {'user': tensor, 'item':
+        tensor}, the buffers the kernel fills for the backward pass (layout in include/gsage.h)."""
         lib = load()
         _dev(indptr, torch.int64, 'indptr', 1)
         _dev(indices, torch.int32, 'indices', 1)
@@ -425,8 +427,24 @@ class Sage2Call:
             raise ValueError("emb must be (%d, %d)" % (2 * self.n_pairs, h2))
         self.hop1 = torch.empty((2 * self.n_pairs, n0), dtype=torch.int32, device=dev) if keep_ids else None
         self.hop2 = torch.empty((2 * self.n_pairs, n0 * n1), dtype=torch.int32, device=dev) if keep_ids else None
+        self._saved = None
+        if saved is not None:
+            rows = self.n_pairs * (1 + n0)
+            shapes = {'x_self': lambda t: (rows, fu if t == 'user' else fi),
+                      'x_mean': lambda t: (rows, fi if t == 'user' else fu),
+                      'h1': lambda t: (rows, h1), 'x_mean1': lambda t: (self.n_pairs, h1),
+                      'z': lambda t: (self.n_pairs, h2)}
+            st = _lib.Sage2Saved()
+            for name, shape in shapes.items():
+                for i, t in enumerate(('user', 'item')):
+                    buf = saved[name][t]
+                    _dev(buf, torch.float32, 'saved[%s][%s]' % (name, t), 2)
+                    if tuple(buf.shape) != shape(t):
+                        raise ValueError("saved[%s][%s] must be %s (got %s)" % (name, t, shape(t), tuple(buf.shape)))
+                    getattr(st, name)[i] = buf.data_ptr()
+            self._saved = st
         self._lib = lib
-        self._keep = [indptr, indices, feat_user, feat_item, weights]
+        self._keep = [indptr, indices, feat_user, feat_item, weights, saved]
         self._tape_len = n0 + n0 * n1
         self._fixed_a = (ptr(indptr), ptr(indices), nu + ni, ptr(feat_user), nu, fu, ptr(feat_item), ni, fi)
         self._fixed_b = (ctypes.byref(self._w[0]), ctypes.byref(self._w[1]), ctypes.byref(self._w[2]),
@@ -449,7 +467,9 @@ class Sage2Call:
                 raise ValueError("replay tape has the wrong length")
         check(self._lib.gs_sage2_forward(*self._fixed_a, ptr(seeds), self.n_pairs, self._n0, self._n1,
                                          int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(walk_id_base) & 0xFFFFFFFFFFFFFFFF,
-                                         ptr(walk_ids), ptr(replay), *self._fixed_b, ptr(err_flag), stream_handle()),
+                                         ptr(walk_ids), ptr(replay), *self._fixed_b,
+                                         ctypes.byref(self._saved) if self._saved is not None else None,
+                                         ptr(err_flag), stream_handle()),
               'gs_sage2_forward')
         return self.emb
 

@@ -1,8 +1,10 @@
 """Static launch plan for one training step of the GraphSAGE stack.
 
-Forward: the sampler kernel, then one fused kernel per (layer, node type) that
-also saves what the backward pass needs (layer 0: the gathered own rows and
-neighbor means, so nothing is gathered twice; layers >= 1: the neighbor means).
+Forward: for two hops, the one-kernel walk forward, which also writes what the
+backward pass reads; for other depths the sampler kernel, then one fused kernel
+per (layer, node type) that saves the same things (layer 0: the gathered own
+rows and neighbor means, so nothing is gathered twice; layers >= 1: the
+neighbor means).
 Backward: per (layer, node type) the MFMA weight-gradient kernel with its
 ordered slab reduction, the input-gradient GEMM for layers >= 1, and the
 broadcast that undoes the dense neighbor mean.  Weight gradients are written
@@ -40,6 +42,25 @@ class SageTrainEngine(SageForwardEngine):
             m.dims[layer][t], m.dims[layer][self.other[t]], m.dims[layer + 1][t], self.h[layer][t].shape[0]),
             dtype=torch.float32, device=dev) for t in _TYPES} for layer in range(self.n_hops)]
         self._train_calls = {}
+        # two hops: sampling, both layers and everything the backward pass reads in ONE kernel
+        f = graph.node_feature_sizes
+        self.walk_train = bool(self.n_hops == 2 and kernels.sage2_supported(
+            f['user'], f['item'], m.dims[1]['user'], m.dims[2]['user'], *self.fanouts))
+        self._walk_train_call = None
+
+    def _forward_walks_train(self, seeds, walk_ids, rng_seed, replay):
+        m = self.model
+        if self._walk_train_call is None:
+            weights = {(l, t): (m._aggs[l][t].w_self, m._aggs[l][t].w_neigh, m._aggs[l][t].bias)
+                       for l in (0, 1) for t in _TYPES}
+            rows = {t: self.h[0][t].shape[0] for t in _TYPES}
+            saved = {'x_self': self.x_self, 'x_mean': {t: self.x_mean[0][t][:rows[t]] for t in _TYPES},
+                     'h1': self.h[0], 'x_mean1': {t: self.x_mean[1][t][:self.batch] for t in _TYPES}, 'z': self.z}
+            self._walk_train_call = kernels.Sage2Call(
+                self.indptr, self.indices, self.tables['user'][0], self.tables['item'][0], self.fanouts, weights,
+                m.normalize == "l2", self.batch, emb=self.emb_all, saved=saved)
+        self._walk_train_call.run(seeds, self.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
+        return self.emb_all[:self.batch], self.emb_all[self.batch:]
 
     # ---- forward ------------------------------------------------------------------
     def _train_call(self, layer, t):
@@ -77,6 +98,8 @@ class SageTrainEngine(SageForwardEngine):
     def forward_train(self, seeds, walk_ids=None, rng_seed=0, replay=None):
         """Returns the (user, item) embeddings; every intermediate the backward
         pass needs stays in the engine's buffers."""
+        if self.walk_train:
+            return self._forward_walks_train(seeds, walk_ids, rng_seed, replay)
         self.sample(seeds, walk_ids, rng_seed, replay)
         for layer in range(self.n_hops):
             for t in _TYPES:

@@ -250,12 +250,31 @@ int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64
  * gs_sage2_supported() != 0 tells whether this build covers the shape; if not,
  * GS_ELIMIT is returned and gs_sample + gs_sage_fused_fwd (or the unfused
  * entry points) compute the same thing.
+ *
+ * saved (nullable): for training, the kernel also writes what the backward pass
+ * reads, so that the forward half of a step stays one launch.  Index 0 = user,
+ * 1 = item.  x_self / x_mean / h1 are tables of n_pairs * (1 + n0) rows per node
+ * type: row p belongs to the root of pair p of that type, row n_pairs + p*n0 + j
+ * to hop-1 head j of the walk rooted at the OTHER type's root of pair p.
+ *   x_self[t]  [rows, F_t]        own feature rows (layer-0 self input)
+ *   x_mean[t]  [rows, F_other(t)] neighbor means (layer-0 neighbor input)
+ *   h1[t]      [rows, H1]         layer-0 output after relu (layer-1 self input)
+ *   x_mean1[t] [n_pairs, H1]      layer-1 neighbor input of the roots
+ *   z[t]       [n_pairs, H2]      layer-1 output before the l2 normalisation
  */
 typedef struct gs_sage_weights {
     const float *w_self;    /* [F_self,  H/2] */
     const float *w_neigh;   /* [F_neigh, H/2] */
     const float *bias;      /* [H] or NULL    */
 } gs_sage_weights;
+
+typedef struct gs_sage2_saved {
+    float *x_self[2];
+    float *x_mean[2];
+    float *h1[2];
+    float *x_mean1[2];
+    float *z[2];
+} gs_sage2_saved;
 
 int gs_sage2_supported(int Fu, int Fi, int H1, int H2, int n0, int n1);
 int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
@@ -268,7 +287,7 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
                      const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
                      int H1, int H2, int normalize,
                      float *emb, int32_t *out_hop1, int32_t *out_hop2,
-                     int32_t *err_flag, void *stream);
+                     const gs_sage2_saved *saved, int32_t *err_flag, void *stream);
 
 /*
  * Link head of the reference's training script: concat(user_emb, item_emb) ->
