@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgsage.so')
+LIB_PATH = os.environ.get('GSAGE_LIB') or os.path.join(_HERE, 'libgsage.so')   # GSAGE_LIB: another build of the same ABI
 
 GS_OK = 0
 GS_MAX_HOPS = 4

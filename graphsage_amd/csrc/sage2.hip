@@ -28,6 +28,12 @@
 // after the weight staging: every LDS hand-off is wave-local.
 #include "gs_common.h"
 
+#ifndef GS_DROP
+#define GS_DROP 0
+#endif
+#ifndef GS_NT
+#define GS_NT 1
+#endif
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -64,6 +70,16 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// Saved activations are written once and read once by the backward pass: streaming stores keep
+// them from displacing feature rows in the caches.
+__device__ __forceinline__ void stream_store(float *dst, const float4 &v) {
+#if GS_NT
+    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(dst));
+#else
+    *reinterpret_cast<float4 *>(dst) = v;
+#endif
+}
 
 // A feature table as the gather loops see it.  BUF: a 128-bit buffer descriptor (tables below
 // 4 GiB): one 32-bit offset register per load and the hardware range check returns zeros for an
@@ -278,13 +294,16 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
                     if (pp < 16) {
                         const float4 mean = make_float4(acc[hd].x / denom, acc[hd].y / denom, acc[hd].z / denom, acc[hd].w / denom);
                         *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) = mean;
-                        if (SAVE && pp < np)
-                            *reinterpret_cast<float4 *>(a.sv_x_mean[1 - side] + (size_t)(sv_h1row + j0 + pp) * FT + 4 * c) = mean;
                     }
                 }
             }
         }
         wave_lds_fence();
+        if (SAVE && !(GS_DROP & 1)) {                          // the tile of neighbor means, out of LDS: np consecutive table rows
+            float *dst = a.sv_x_mean[1 - side] + (size_t)(sv_h1row + j0) * FT;
+            for (int i = lane; i < np * FTV; i += 64)
+                stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(A + (i / FTV) * LDA + 4 * (i % FTV)));
+        }
         f32x4 acc_s[NT1], acc_n[NT1];
 #pragma unroll
         for (int ct = 0; ct < NT1; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -294,8 +313,8 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         for (int pass = 0; pass < NPASS_O; ++pass) {
             const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
             *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = own[pass];
-            if (SAVE && rr < np)
-                *reinterpret_cast<float4 *>(a.sv_x_self[1 - side] + (size_t)(sv_h1row + j0 + rr) * FO + 4 * c) = own[pass];
+            if (SAVE && !(GS_DROP & 2) && rr < np)
+                stream_store(a.sv_x_self[1 - side] + (size_t)(sv_h1row + j0 + rr) * FO + 4 * c, own[pass]);
             rootsum.x += own[pass].x; rootsum.y += own[pass].y; rootsum.z += own[pass].z; rootsum.w += own[pass].w;
         }
         wave_lds_fence();
@@ -331,9 +350,9 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         if (lane < FOV) {
             const float4 mean = make_float4(rootsum.x / d0, rootsum.y / d0, rootsum.z / d0, rootsum.w / d0);
             *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
-            if (SAVE) *reinterpret_cast<float4 *>(a.sv_x_mean[side] + (size_t)pair * FO + 4 * lane) = mean;
+            if (SAVE) stream_store(a.sv_x_mean[side] + (size_t)pair * FO + 4 * lane, mean);
         }
-        if (SAVE && lane < FTV) *reinterpret_cast<float4 *>(a.sv_x_self[side] + (size_t)pair * FT + 4 * lane) = own_root;
+        if (SAVE && lane < FTV) stream_store(a.sv_x_self[side] + (size_t)pair * FT + 4 * lane, own_root);
         wave_lds_fence();
         f32x4 acc_s[NT1], acc_n[NT1];
 #pragma unroll
@@ -371,15 +390,15 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         if (lane < H1V) {
             const float4 mean = make_float4(s.x / d0, s.y / d0, s.z / d0, s.w / d0);
             *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
-            if (SAVE) *reinterpret_cast<float4 *>(a.sv_x_mean1[side] + (size_t)pair * H1 + 4 * lane) = mean;
+            if (SAVE) stream_store(a.sv_x_mean1[side] + (size_t)pair * H1 + 4 * lane, mean);
         }
-        if (SAVE) {
+        if (SAVE && !(GS_DROP & 4)) {
             // layer-0 activations: the root's row, then the hop-1 heads' rows as one contiguous block (LDH == H1)
             if (lane < H1V)
-                *reinterpret_cast<float4 *>(a.sv_h1[side] + (size_t)pair * H1 + 4 * lane) = *reinterpret_cast<const float4 *>(H1t + 4 * lane);
+                stream_store(a.sv_h1[side] + (size_t)pair * H1 + 4 * lane, *reinterpret_cast<const float4 *>(H1t + 4 * lane));
             float *dst = a.sv_h1[1 - side] + (size_t)sv_h1row * H1;
             for (int i = lane; i < n0 * H1V; i += 64)
-                *reinterpret_cast<float4 *>(dst + 4 * i) = *reinterpret_cast<const float4 *>(H1t + LDH + 4 * i);
+                stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(H1t + LDH + 4 * i));
         }
         wave_lds_fence();
         f32x4 acc_s[NT2], acc_n[NT2];
@@ -454,7 +473,9 @@ void sage2_kernel(const Sage2Args a) {
     }
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index as a scalar: everything derived from it (walk number, root, LDS bases, output
+    // rows) then lives in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int per_wave = 16 * LDA + a.h1_rows * LDH + a.ids_per_wave;
     float *A = wave0 + (size_t)wave * per_wave;
     float *H1t = A + 16 * LDA;

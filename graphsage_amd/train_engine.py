@@ -116,6 +116,16 @@ class SageTrainEngine(SageForwardEngine):
                 self.emb[t].copy_(self.z[t])
         return self.emb['user'], self.emb['item']
 
+    def _g_self_dst(self, layer, t, g_prev):
+        """Where the own-row input gradient of (layer, type) goes.  With one head
+        segment (the roots, rows [0, B)) that is nobody's neighbor slot, it is the
+        roots' part of the previous layer's gradient itself; otherwise a buffer
+        that is added to the neighbor contribution afterwards."""
+        heads = [(s, h, r0, n) for (s, h, side, r0, n) in self.segments[t] if h <= self.n_hops - 1 - layer]
+        if len(heads) == 1 and heads[0][1] == 0 and heads[0][2] == 0:
+            return g_prev[t][:heads[0][3]]
+        return self.g_xs[layer][t]
+
     # ---- backward -----------------------------------------------------------------
     def backward(self, g_user, g_item):
         """Gradients of every aggregator weight from the embedding gradients; they
@@ -142,7 +152,7 @@ class SageTrainEngine(SageForwardEngine):
                     need_x_self=layer > 0, need_x_mean=layer > 0, need_bias=agg.bias is not None,
                     g_w_self=agg.w_self.grad, g_w_neigh=agg.w_neigh.grad,
                     g_bias=None if agg.bias is None else agg.bias.grad,
-                    g_x_self=self.g_xs[layer][t] if layer > 0 else None,
+                    g_x_self=self._g_self_dst(layer, t, g_prev) if layer > 0 else None,
                     g_x_mean=self.g_xm[layer][t] if layer > 0 else None, workspace=self.ws[layer][t])
             if layer == 0:
                 break
@@ -158,10 +168,10 @@ class SageTrainEngine(SageForwardEngine):
                         _, p0, pn = self.where[s - 2]
                         kernels.gather_mean_bwd(self.g_xm[layer][other[t]][p0:p0 + pn], None, self.fanouts[h - 1], dst)
                         wrote = True
-                    if h <= L - 1 - layer:                 # head slot at this layer
-                        src = self.g_xs[layer][t][r0:r0 + n]
+                    if h <= L - 1 - layer:                 # head slot at this layer: its own-row gradient
                         if wrote:
-                            dst.add_(src)
-                        else:
-                            dst.copy_(src)
+                            dst.add_(self.g_xs[layer][t][r0:r0 + n])
+                        elif self._g_self_dst(layer, t, g_prev) is self.g_xs[layer][t]:
+                            dst.copy_(self.g_xs[layer][t][r0:r0 + n])
+                        # else: the projection backward wrote the roots' rows in place
             g_out = {t: g_prev[t] for t in _TYPES}
