@@ -247,9 +247,9 @@ def main():
         if tr is not None:
             tgt = (torch.arange(b, device=device) % 2).to(torch.float32)
 
-            # one GPU: the step's launches are replayed from a captured HIP graph; several GPUs: plain
-            # stream-ordered launches with the RCCL all-reduce between backward and update
-            step_fn = tr.step_graph if world == 1 else tr.step_device
+            # the step's launches are replayed from a captured HIP graph; with several GPUs the graph
+            # ends after backward, the RCCL all-reduce and the update follow it on the stream
+            step_fn = tr.step_device if os.environ.get('BENCH_EAGER_TRAIN') else tr.step_graph
 
             def tstep(i):
                 k = my_batches[i % len(my_batches)]
@@ -278,7 +278,7 @@ def main():
             train = {"value": args.train_steps * b * world / t_el, "unit": "seed edges/s",
                      "ms_per_step": t_el / args.train_steps * 1e3, "steps": args.train_steps,
                      "what": "sample + fwd + bwd + flat-bucket all-reduce (RCCL for N>1) + Adam, MSE on concat->Dense(1,sigmoid)"
-                             + ("; launches replayed from a captured HIP graph" if world == 1 else "")}
+                             + ("" if os.environ.get('BENCH_EAGER_TRAIN') else "; launches replayed from a captured HIP graph")}
 
     guard.cancel()
     if rank == 0:
