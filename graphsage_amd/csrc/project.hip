@@ -169,11 +169,23 @@ void rows_gemm_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
 // four MFMAs and a wave's read is one contiguous 1 KB.  Within a 16-wide half of
 // the k slice, lane quarter q multiplies k = 4q + step at step 0..3 (any split of
 // k over (quarter, step) sums the same products).
-constexpr int GB_M = 128, GB_N = 128, GB_K = 32;
+#ifndef GS_GB_K
+#define GS_GB_K 32
+#endif
+#ifndef GS_GB_BLOCKS
+#define GS_GB_BLOCKS 2
+#endif
+constexpr int GB_M = 128, GB_N = 128, GB_K = GS_GB_K;   // k slice: 16 or 32
+constexpr int GB_KQ = GB_K / 4;                         // groups of four k per slice
+constexpr int GB_NP = GB_KQ / 2;                        // 16-byte pieces of A (and of B) a thread stages per slice
+constexpr int GB_NR = 16 / GB_KQ;                       // rows of A one 16-lane group covers while staging
 constexpr int GB_TILE = GB_M * GB_K;                    // floats of one A (or B) stage
-constexpr size_t GB_LDS = size_t(4) * GB_TILE * sizeof(float);   // A and B, two stages each
+constexpr int GB_EP_LD = GB_N + 4;                      // epilogue row stride: the four lane quarters land 16 banks apart
+constexpr size_t GB_LDS_LOOP = size_t(4) * GB_TILE * sizeof(float);   // A and B, two stages each
+constexpr size_t GB_LDS_EPI = size_t(64) * GB_EP_LD * sizeof(float);
+constexpr size_t GB_LDS = GB_LDS_LOOP > GB_LDS_EPI ? GB_LDS_LOOP : GB_LDS_EPI;
 
-__global__ __launch_bounds__(kThreads, 2)
+__global__ __launch_bounds__(kThreads, GS_GB_BLOCKS)
 void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     extern __shared__ __align__(16) float gb_smem[];
     const int ncb0 = s0.N / GB_N;
@@ -191,23 +203,27 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     const int wave = tid >> 6, lane = tid & 63;
     const int wave_m = wave & 1, wave_n = wave >> 1;
 
-    // staging roles.  A: 8 lanes cover one row's 128-byte slice, 32 rows per pass, 4 passes.
-    const int a_kq = tid & 7;
-    const float *a_src[4];
-    int a_dst[4];
+    // staging roles.  A: GB_KQ lanes cover one row's slice (16 bytes each), 256/GB_KQ rows per pass.
+    const int a_kq = tid % GB_KQ;
+    const float *a_src[GB_NP];
+    int a_dst[GB_NP];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int row = p * 32 + (tid >> 3);
+    for (int p = 0; p < GB_NP; ++p) {
+        const int row = p * (kThreads / GB_KQ) + tid / GB_KQ;
         int64_t grow = row0 + row;
         if (grow > M - 1) grow = M - 1;                 // rows past the end repeat the last one; never stored
         a_src[p] = A + grow * lda + a_kq * 4;
-        a_dst[p] = ((a_kq >> 2) * 8 + (row >> 4)) * 256 + ((a_kq & 3) * 16 + (row & 15)) * 4;
+        // within a fragment block the 16 slots of a lane quarter are rotated by GB_NR * (k quad): the
+        // 16-lane groups of this write (GB_NR rows x GB_KQ k quads) and of the fragment read (sixteen
+        // rows of one quad) then both touch sixteen different 16-byte bank groups
+        a_dst[p] = ((a_kq >> 2) * 8 + (row >> 4)) * 256 +
+                   ((a_kq & 3) * 16 + (((row & 15) + GB_NR * a_kq) & 15)) * 4;
     }
     // B: a thread gathers four consecutive k of one column (4 scalar loads, coalesced over columns)
-    const float *b_src[4];
-    int b_dst[4];
+    const float *b_src[GB_NP];
+    int b_dst[GB_NP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < GB_NP; ++j) {
         const int idx = j * 256 + tid;
         const int col = idx & 127, kquad = idx >> 7;
         b_src[j] = B + (int64_t)(kquad * 4) * ldbk + col0 + col;
@@ -219,9 +235,12 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's (rotated) slot in an A fragment block, per half of the k slice
+    const int a_slot[2] = {(lane >> 4) * 16 + (((lane & 15) + GB_NR * (lane >> 4)) & 15),
+                           (lane >> 4) * 16 + (((lane & 15) + GB_NR * ((lane >> 4) + 4)) & 15)};
 
     // the slice in flight lives in named registers (an indexed array here ends up in scratch)
-    float4 ar0, ar1, ar2, ar3, br0, br1, br2, br3;
+    float4 ar0, ar1, ar2 = make_float4(0.f, 0.f, 0.f, 0.f), ar3 = ar2, br0, br1, br2 = ar2, br3 = ar2;
 #define GB_LOAD_B(dst_, j_, k0_)                                                                   \
     {                                                                                              \
         const float *src = b_src[j_] + (int64_t)(k0_) * ldbk;                                      \
@@ -232,21 +251,26 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
         const int k0 = (k0_);                                                                      \
         ar0 = *reinterpret_cast<const float4 *>(a_src[0] + k0);                                    \
         ar1 = *reinterpret_cast<const float4 *>(a_src[1] + k0);                                    \
-        ar2 = *reinterpret_cast<const float4 *>(a_src[2] + k0);                                    \
-        ar3 = *reinterpret_cast<const float4 *>(a_src[3] + k0);                                    \
-        GB_LOAD_B(br0, 0, k0) GB_LOAD_B(br1, 1, k0) GB_LOAD_B(br2, 2, k0) GB_LOAD_B(br3, 3, k0)    \
+        if constexpr (GB_NP == 4) {                                                                \
+            ar2 = *reinterpret_cast<const float4 *>(a_src[GB_NP - 2] + k0);                        \
+            ar3 = *reinterpret_cast<const float4 *>(a_src[GB_NP - 1] + k0);                        \
+        }                                                                                          \
+        GB_LOAD_B(br0, 0, k0) GB_LOAD_B(br1, 1, k0)                                                \
+        if constexpr (GB_NP == 4) { GB_LOAD_B(br2, GB_NP - 2, k0) GB_LOAD_B(br3, GB_NP - 1, k0) }  \
     }
 #define GB_STORE_SLICE(stage_)                                                                     \
     {                                                                                              \
         float *As_w = gb_smem + (stage_) * 2 * GB_TILE, *Bs_w = As_w + GB_TILE;                    \
         *reinterpret_cast<float4 *>(As_w + a_dst[0]) = ar0;                                        \
         *reinterpret_cast<float4 *>(As_w + a_dst[1]) = ar1;                                        \
-        *reinterpret_cast<float4 *>(As_w + a_dst[2]) = ar2;                                        \
-        *reinterpret_cast<float4 *>(As_w + a_dst[3]) = ar3;                                        \
         *reinterpret_cast<float4 *>(Bs_w + b_dst[0]) = br0;                                        \
         *reinterpret_cast<float4 *>(Bs_w + b_dst[1]) = br1;                                        \
-        *reinterpret_cast<float4 *>(Bs_w + b_dst[2]) = br2;                                        \
-        *reinterpret_cast<float4 *>(Bs_w + b_dst[3]) = br3;                                        \
+        if constexpr (GB_NP == 4) {                                                                \
+            *reinterpret_cast<float4 *>(As_w + a_dst[GB_NP - 2]) = ar2;                            \
+            *reinterpret_cast<float4 *>(As_w + a_dst[GB_NP - 1]) = ar3;                            \
+            *reinterpret_cast<float4 *>(Bs_w + b_dst[GB_NP - 2]) = br2;                            \
+            *reinterpret_cast<float4 *>(Bs_w + b_dst[GB_NP - 1]) = br3;                            \
+        }                                                                                          \
     }
 
     GB_LOAD_SLICE(0);
@@ -260,11 +284,11 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
         __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the multiply (the scheduler would sink them)
         const float *As = gb_smem + stage * 2 * GB_TILE, *Bs = As + GB_TILE;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < GB_K / 16; ++half) {
             f32x4 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const f32x4 *>(As + (half * 8 + wave_m * 4 + i) * 256 + lane * 4);
+                a[i] = *reinterpret_cast<const f32x4 *>(As + (half * 8 + wave_m * 4 + i) * 256 + a_slot[half] * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 b[j] = *reinterpret_cast<const f32x4 *>(Bs + (half * 8 + wave_n * 4 + j) * 256 + lane * 4);
@@ -284,29 +308,46 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
 #undef GB_LOAD_B
 #undef GB_STORE_SLICE
 
+    // Epilogue through LDS, 64 rows at a time: accumulators (+ bias, activation) are laid out as
+    // rows of the output tile, then every thread writes 16-byte pieces of whole rows (a row of the
+    // tile is 512 contiguous bytes of the output) instead of sixty-four 4-byte stores per lane.
+    constexpr int EP_LD = GB_EP_LD;
     const int r = lane & 15, q = lane >> 4;
+    float bv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = col0 + wave_n * 64 + j * 16 + r;
-        const float bv = bias ? bias[col] : 0.f;
+    for (int j = 0; j < 4; ++j) bv[j] = bias ? bias[col0 + wave_n * 64 + j * 16 + r] : 0.f;
+#pragma unroll 1
+    for (int hm = 0; hm < 2; ++hm) {
+        if (wave_m == hm) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t grow = row0 + wave_m * 64 + i * 16 + q * 4 + e;
-                if (grow < M) {
-                    float v = acc[i][j][e] + bv;
-                    if (act == GS_ACT_RELU) v = fmaxf(v, 0.f);
-                    outp[grow * ldo + col] = v;
-                }
-            }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][e] + bv[j];
+                        if (act == GS_ACT_RELU) v = fmaxf(v, 0.f);
+                        gb_smem[(i * 16 + q * 4 + e) * EP_LD + wave_n * 64 + j * 16 + r] = v;
+                    }
         }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * kThreads + tid;          // 64 rows x 32 float4
+            const int row = idx >> 5, c4 = (idx & 31) * 4;
+            const int64_t grow = row0 + hm * 64 + row;
+            if (grow < M)
+                *reinterpret_cast<float4 *>(outp + grow * ldo + col0 + c4) =
+                    *reinterpret_cast<const float4 *>(gb_smem + row * EP_LD + c4);
+        }
+        __syncthreads();
     }
 }
 
 inline bool big_gemm_applies(const GemmSide &s) {
     return s.vec && s.K % GB_K == 0 && s.N % GB_N == 0 && s.ldbn == 1 && !s.mask &&
-           (reinterpret_cast<uintptr_t>(s.A) & 15) == 0 && s.lda % 4 == 0;
+           (reinterpret_cast<uintptr_t>(s.A) & 15) == 0 && s.lda % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(s.out) & 15) == 0 && s.ldo % 4 == 0;
 }
 
 // ---- weight / bias gradient ------------------------------------------------
