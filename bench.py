@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: seed edges/s of the 2-hop sample+aggregate forward pass.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg5|ml1m]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5|ml1m]
 
 A step = one batch of B seed edges through the hot path with every input already
 in HBM: sampler kernel (Philox draws) -> feature gathers and fused gather-mean ->
@@ -28,6 +28,9 @@ WORKLOADS = {
     'cfg3': dict(nu=10_000_000, ni=1_000_000, e=500_000_000, fu=64, fi=64, fan=[25, 10], layers=[32, 32],
                  alpha_item=1.3, alpha_user=1.3,
                  desc="synthetic power-law bipartite 10M x 1M, 500M edges, 64-d features, 2-hop [25,10]"),
+    'cfg4': dict(nu=100_000_000, ni=10_000_000, e=2_000_000_000, fu=64, fi=64, fan=[25, 10], layers=[32, 32],
+                 alpha_item=1.1, alpha_user=None,
+                 desc="synthetic bipartite 100M users x 10M items, 2B edges (4e9 CSR entries), 64-d features, 2-hop [25,10]"),
     'cfg5': dict(nu=1_000_000, ni=100_000, e=50_000_000, fu=256, fi=256, fan=[25, 10, 5], layers=[256, 256, 256],
                  alpha_item=1.1, alpha_user=None,
                  desc="cfg2 graph, 3-hop [25,10,5], 256-d features, 256 hidden"),

@@ -158,3 +158,31 @@ def test_sampler_addresses_neighbor_arrays_beyond_32_bit_offsets(cuda):
     assert int(indptr[1954]) > 2 ** 32
     del indices
     torch.cuda.empty_cache()
+
+
+def test_walk_kernel_reads_feature_tables_beyond_4_gib_with_plain_loads(cuda):
+    """A user table of 17.5 M rows x 64 floats (4.5 GB) is past what a buffer
+    descriptor addresses, so the one-kernel forward takes its 64-bit load path;
+    it must agree with the general kernels."""
+    if torch.cuda.get_device_properties(0).total_memory < 40 * 2 ** 30:
+        pytest.skip("needs about 12 GB of device memory")
+    nu, ni, e, b = 17_500_000, 50_000, 40_000_000, 512
+    g, u, it = synthetic.power_law_bipartite(nu, ni, e, 64, 64, alpha_item=1.0, seed=5, device=cuda)
+    assert g.device_tensors()['user'].numel() * 4 > 2 ** 32
+    gen = ga.GraphSAGEGenerator(g, b, [25, 10], head_node_types=['user', 'item'], seed=1)
+    model = ga.GraphSAGE([32, 32], gen, seed=3).build()
+    # roots from the top of the id range: their rows lie beyond the 4 GiB mark
+    pick = torch.argsort(u[:2_000_000], descending=True)[:b]
+    seeds = torch.cat([u[pick], it[pick]]).contiguous()
+    assert int(seeds[:b].min()) * 256 > 2 ** 32
+    walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda)
+    eng_w = SageForwardEngine(g, model, b)
+    eng_u = SageForwardEngine(g, model, b, use_fused=False)
+    assert eng_w.walk_kernel
+    out_w = [x.clone() for x in eng_w.forward(seeds, walk_ids, rng_seed=3)]
+    out_u = [x.clone() for x in eng_u.forward(seeds, walk_ids, rng_seed=3)]
+    assert eng_w.err_flag.tolist() == [0, 0]
+    for k in range(2):
+        assert (out_w[k] - out_u[k]).abs().max().item() <= 1e-5
+    del g, u, it, eng_w, eng_u
+    torch.cuda.empty_cache()
