@@ -64,6 +64,31 @@ if traffic:
         w, _ = d.get('write', (0.0, 0))
         lines.append('| %s | %d | %.2f | %.2f | %.2f |' % (k, nf, f / 1e6, 2 * f / 1e6, w / 1e6))
     lines.append('')
+sq_files = sorted(glob.glob(os.path.join(src, 'sq', '*', '*counter_collection.csv')), key=os.path.getmtime, reverse=True)
+if sq_files:
+    # per kernel: the launch with the most wave cycles (the largest shape of that kernel)
+    per = defaultdict(lambda: defaultdict(dict))
+    for r in csv.DictReader(open(sq_files[0])):
+        if any(o in r['Kernel_Name'] for o in ours):
+            per[short(r['Kernel_Name'])][r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
+    lines += ['## wave states and matrix-pipe use (rocprofv3 --pmc, SQ + GRBM pass; largest launch of each kernel)', '',
+              'SQ_WAVE_CYCLES and SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts '
+              'cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE / 8 is the launch length in shader cycles.', '',
+              '| kernel | parked (s_waitcnt, barrier) | issue stall | issuing | MFMA pipe busy | LDS bank-conflict cycles / wave cycle |',
+              '|---|---|---|---|---|---|']
+    for k, d in sorted(per.items()):
+        best = max(d.values(), key=lambda c: c.get('SQ_WAVE_CYCLES', 0.0))
+        wc = best.get('SQ_WAVE_CYCLES', 0.0)
+        if wc <= 0:
+            continue
+        cyc = best.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
+        mf = best.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
+        lines.append('| %s | %.0f %% | %.0f %% | %.0f %% | %s | %.3f |' % (
+            k, 100 * best.get('SQ_WAIT_ANY', 0) / wc, 100 * best.get('SQ_WAIT_INST_ANY', 0) / wc,
+            100 * best.get('SQ_ACTIVE_INST_ANY', 0) / wc,
+            ('%.0f %% of %.0f k cycles' % (100 * mf / (1024 * cyc), cyc / 1e3)) if cyc > 0 and mf > 0 else '-',
+            best.get('SQ_LDS_BANK_CONFLICT', 0) / (4 * wc)))
+    lines.append('')
 os.makedirs(os.path.join(root, 'profiles'), exist_ok=True)
 with open(os.path.join(root, 'profiles', name + '.md'), 'w') as fh:
     fh.write('\n'.join(lines) + '\n')
