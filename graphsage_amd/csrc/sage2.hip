@@ -109,6 +109,23 @@ struct RowTable {
         const float4 t = *reinterpret_cast<const float4 *>(base + (size_t)(ok ? row : 0u) * row_bytes + col);
         return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // What the deepest hop keeps in LDS per sampled node.  BUF: the row's byte offset in the
+    // table, or kNoRow for an id outside it, so that the gather loop spends one OR and one select
+    // per load (the range check was paid once, here); !BUF: the row number.
+    static constexpr unsigned kNoRow = 0xFFFFF000u;       // + any column offset stays out of range, without wrapping
+    __device__ __forceinline__ int32_t entry(int32_t id, int id_offset, int row_bytes) const {
+        const unsigned row = (unsigned)(id - id_offset);
+        if (BUF) return (int32_t)(row < (unsigned)rows ? row * (unsigned)row_bytes : kNoRow);
+        return (int32_t)row;
+    }
+    __device__ __forceinline__ float4 load_entry(bool want, int32_t e, unsigned col, int row_bytes) const {
+        if (BUF) {
+            const unsigned off = want ? ((unsigned)e | col) : kNoRow;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+            return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+        return load(want, (unsigned)e, col, row_bytes);
+    }
 };
 
 // D[16 x 16*NT] += A[16 x K] . W[K x 16*NT]; A in LDS (row stride lda), W in fragment order.
@@ -225,7 +242,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             for (int c = 0; c < kChunks; ++c) {
                 const int t = base + c * 64 + lane;
                 if (t < total) {
-                    hop2[t] = v[c];
+                    hop2[t] = tabT.entry(v[c], offT, FT * 4);
                     if (a.out_hop2) a.out_hop2[(size_t)w * total + t] = v[c];
                 }
             }
@@ -277,7 +294,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
 #pragma unroll
                         for (int u = 0; u < kUnroll; ++u) {
                             const bool want = (pp < np) && (u < per) && (c0 + u < n1);
-                            v[hd][u] = tabT.load(want, (unsigned)(cid[u] - offT), col, FT * 4);
+                            v[hd][u] = tabT.load_entry(want, cid[u], col, FT * 4);
                         }
                     }
 #pragma unroll
@@ -530,7 +547,7 @@ int launch_one(const Sage2Args &a, hipStream_t stream) {
 template <int FU, int FI, int HH1, int HH2>
 int launch(const Sage2Args &a, hipStream_t stream) {
     // buffer addressing needs both tables inside a 4 GiB window
-    const long long lim = 0xFFFFFFF0LL;
+    const long long lim = 0xFFFFF000LL;                  // RowTable::kNoRow must lie past the end of both tables
     const bool buf = a.n_rows[0] * FU * 4 < lim && a.n_rows[1] * FI * 4 < lim;
     if (a.sv_z[0]) return buf ? launch_one<FU, FI, HH1, HH2, true, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, true>(a, stream);
     return buf ? launch_one<FU, FI, HH1, HH2, true, false>(a, stream) : launch_one<FU, FI, HH1, HH2, false, false>(a, stream);
