@@ -169,9 +169,7 @@ void rows_gemm_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
 // four MFMAs and a wave's read is one contiguous 1 KB.  Within a 16-wide half of
 // the k slice, lane quarter q multiplies k = 4q + step at step 0..3 (any split of
 // k over (quarter, step) sums the same products).
-#ifndef GS_GB_K
 #define GS_GB_K 32
-#endif
 #ifndef GS_GB_BLOCKS
 #define GS_GB_BLOCKS 2
 #endif
@@ -273,37 +271,65 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
         }                                                                                          \
     }
 
+    // Fragment registers in two named sets: while one set feeds the matrix pipe the other is being
+    // read from LDS, so neither the LDS latency nor the barrier sits between two runs of MFMAs.
+    //   per slice t:  read Y <- second half of slice t | MFMA X (first half) | store slice t+1 to the
+    //                 other stage, barrier | global loads (slice t+2) | read X <- first half of slice
+    //                 t+1 | MFMA Y (second half)
+    // The stage written in iteration t was last read (both halves) before the barrier of
+    // iteration t-1, which every wave has passed.
+    f32x4 aX0, aX1, aX2, aX3, bX0, bX1, bX2, bX3, aY0, aY1, aY2, aY3, bY0, bY1, bY2, bY3;
+#define GB_READ(S_, stage_, half_)                                                                  \
+    {                                                                                              \
+        const float *As_r = gb_smem + (stage_) * 2 * GB_TILE + ((half_) * 8 + wave_m * 4) * 256 + a_slot[half_] * 4; \
+        const float *Bs_r = gb_smem + (stage_) * 2 * GB_TILE + GB_TILE + ((half_) * 8 + wave_n * 4) * 256 + lane * 4; \
+        a##S_##0 = *reinterpret_cast<const f32x4 *>(As_r);                                         \
+        b##S_##0 = *reinterpret_cast<const f32x4 *>(Bs_r);                                         \
+        a##S_##1 = *reinterpret_cast<const f32x4 *>(As_r + 256);                                   \
+        b##S_##1 = *reinterpret_cast<const f32x4 *>(Bs_r + 256);                                   \
+        a##S_##2 = *reinterpret_cast<const f32x4 *>(As_r + 512);                                   \
+        b##S_##2 = *reinterpret_cast<const f32x4 *>(Bs_r + 512);                                   \
+        a##S_##3 = *reinterpret_cast<const f32x4 *>(As_r + 768);                                   \
+        b##S_##3 = *reinterpret_cast<const f32x4 *>(Bs_r + 768);                                   \
+    }
+#define GB_MFMA_ROW(i_, av_, S_, st_)                                                              \
+    acc[i_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], b##S_##0[st_], acc[i_][0], 0, 0, 0); \
+    acc[i_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], b##S_##1[st_], acc[i_][1], 0, 0, 0); \
+    acc[i_][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], b##S_##2[st_], acc[i_][2], 0, 0, 0); \
+    acc[i_][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], b##S_##3[st_], acc[i_][3], 0, 0, 0);
+#define GB_MFMA(S_)                                                                                \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                             \
+        GB_MFMA_ROW(0, a##S_##0, S_, st) GB_MFMA_ROW(1, a##S_##1, S_, st)                          \
+        GB_MFMA_ROW(2, a##S_##2, S_, st) GB_MFMA_ROW(3, a##S_##3, S_, st)                          \
+    }
+
+    static_assert(GB_K == 32, "the pipelined main loop walks two 16-wide halves per slice");
     GB_LOAD_SLICE(0);
     GB_STORE_SLICE(0);
     __syncthreads();
+    GB_READ(X, 0, 0);
     const int n_slices = K / GB_K;
+    GB_LOAD_SLICE(min(1, n_slices - 1) * GB_K);
     for (int kt = 0; kt < n_slices; ++kt) {
         const int stage = kt & 1;
-        // next slice in flight during the multiply; the last iteration re-reads its own slice (unused)
-        GB_LOAD_SLICE(min(kt + 1, n_slices - 1) * GB_K);
-        __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the multiply (the scheduler would sink them)
-        const float *As = gb_smem + stage * 2 * GB_TILE, *Bs = As + GB_TILE;
-#pragma unroll
-        for (int half = 0; half < GB_K / 16; ++half) {
-            f32x4 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const f32x4 *>(As + (half * 8 + wave_m * 4 + i) * 256 + a_slot[half] * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                b[j] = *reinterpret_cast<const f32x4 *>(Bs + (half * 8 + wave_n * 4 + j) * 256 + lane * 4);
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][st], b[j][st], acc[i][j], 0, 0, 0);
-        }
+        GB_READ(Y, stage, 1);
+        __builtin_amdgcn_sched_barrier(0);  // LDS reads are issued ahead of the multiply
+        GB_MFMA(X);
         __builtin_amdgcn_sched_barrier(0);
-        GB_STORE_SLICE(stage ^ 1);          // that stage was last read before the previous barrier
+        GB_STORE_SLICE(stage ^ 1);          // slice kt+1, loaded one whole iteration ago
         __syncthreads();
+        // slice kt+2 goes in flight now and is stored after the next iteration's first multiply; past
+        // the end the last slice is re-read (unused)
+        GB_LOAD_SLICE(min(kt + 2, n_slices - 1) * GB_K);
+        GB_READ(X, stage ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        GB_MFMA(Y);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();                        // every wave is done with the stages before the epilogue reuses them
+#undef GB_READ
+#undef GB_MFMA_ROW
+#undef GB_MFMA
 #undef GB_LOAD_SLICE
 #undef GB_LOAD_B
 #undef GB_STORE_SLICE
