@@ -169,11 +169,7 @@ void rows_gemm_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
 // four MFMAs and a wave's read is one contiguous 1 KB.  Within a 16-wide half of
 // the k slice, lane quarter q multiplies k = 4q + step at step 0..3 (any split of
 // k over (quarter, step) sums the same products).
-#define GS_GB_K 32
-#ifndef GS_GB_BLOCKS
-#define GS_GB_BLOCKS 2
-#endif
-constexpr int GB_M = 128, GB_N = 128, GB_K = GS_GB_K;   // k slice: 16 or 32
+constexpr int GB_M = 128, GB_N = 128, GB_K = 32;
 constexpr int GB_KQ = GB_K / 4;                         // groups of four k per slice
 constexpr int GB_NP = GB_KQ / 2;                        // 16-byte pieces of A (and of B) a thread stages per slice
 constexpr int GB_NR = 16 / GB_KQ;                       // rows of A one 16-lane group covers while staging
@@ -183,7 +179,7 @@ constexpr size_t GB_LDS_LOOP = size_t(4) * GB_TILE * sizeof(float);   // A and B
 constexpr size_t GB_LDS_EPI = size_t(64) * GB_EP_LD * sizeof(float);
 constexpr size_t GB_LDS = GB_LDS_LOOP > GB_LDS_EPI ? GB_LDS_LOOP : GB_LDS_EPI;
 
-__global__ __launch_bounds__(kThreads, GS_GB_BLOCKS)
+__global__ __launch_bounds__(kThreads, 2)
 void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     extern __shared__ __align__(16) float gb_smem[];
     const int ncb0 = s0.N / GB_N;

@@ -28,12 +28,6 @@
 // after the weight staging: every LDS hand-off is wave-local.
 #include "gs_common.h"
 
-#ifndef GS_DROP
-#define GS_DROP 0
-#endif
-#ifndef GS_NT
-#define GS_NT 1
-#endif
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -74,11 +68,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 // Saved activations are written once and read once by the backward pass: streaming stores keep
 // them from displacing feature rows in the caches.
 __device__ __forceinline__ void stream_store(float *dst, const float4 &v) {
-#if GS_NT
     __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(dst));
-#else
-    *reinterpret_cast<float4 *>(dst) = v;
-#endif
 }
 
 // A feature table as the gather loops see it.  BUF: a 128-bit buffer descriptor (tables below
@@ -316,7 +306,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             }
         }
         wave_lds_fence();
-        if (SAVE && !(GS_DROP & 1)) {                          // the tile of neighbor means, out of LDS: np consecutive table rows
+        if (SAVE) {                          // the tile of neighbor means, out of LDS: np consecutive table rows
             float *dst = a.sv_x_mean[1 - side] + (size_t)(sv_h1row + j0) * FT;
             for (int i = lane; i < np * FTV; i += 64)
                 stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(A + (i / FTV) * LDA + 4 * (i % FTV)));
@@ -330,7 +320,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         for (int pass = 0; pass < NPASS_O; ++pass) {
             const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
             *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = own[pass];
-            if (SAVE && !(GS_DROP & 2) && rr < np)
+            if (SAVE && rr < np)
                 stream_store(a.sv_x_self[1 - side] + (size_t)(sv_h1row + j0 + rr) * FO + 4 * c, own[pass]);
             rootsum.x += own[pass].x; rootsum.y += own[pass].y; rootsum.z += own[pass].z; rootsum.w += own[pass].w;
         }
@@ -409,7 +399,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
             if (SAVE) stream_store(a.sv_x_mean1[side] + (size_t)pair * H1 + 4 * lane, mean);
         }
-        if (SAVE && !(GS_DROP & 4)) {
+        if (SAVE) {
             // layer-0 activations: the root's row, then the hop-1 heads' rows as one contiguous block (LDH == H1)
             if (lane < H1V)
                 stream_store(a.sv_h1[side] + (size_t)pair * H1 + 4 * lane, *reinterpret_cast<const float4 *>(H1t + 4 * lane));
