@@ -42,6 +42,7 @@ class SageTrainEngine(SageForwardEngine):
             m.dims[layer][t], m.dims[layer][self.other[t]], m.dims[layer + 1][t], self.h[layer][t].shape[0]),
             dtype=torch.float32, device=dev) for t in _TYPES} for layer in range(self.n_hops)]
         self._train_calls = {}
+        self._side = None                                       # second stream of the backward pass
         # two hops: sampling, both layers and everything the backward pass reads in ONE kernel
         f = graph.node_feature_sizes
         self.walk_train = bool(self.n_hops == 2 and kernels.sage2_supported(
@@ -130,48 +131,65 @@ class SageTrainEngine(SageForwardEngine):
     def backward(self, g_user, g_item):
         """Gradients of every aggregator weight from the embedding gradients; they
         are written into ``param.grad`` (which must exist, e.g. as views of a
-        flat bucket) and overwrite what was there."""
+        flat bucket) and overwrite what was there.
+
+        Within a layer the two node types do not depend on each other, so their
+        kernels -- small, latency-bound launches -- run on two streams (user on
+        the caller's, item on a side stream) and meet where one type's gradient
+        feeds the other's neighbor slots.  A HIP graph captured around this call
+        records the same fork/join."""
         m, other, L = self.model, self.other, self.n_hops
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        streams = {'user': main, 'item': self._side}
         g_emb = {'user': g_user.contiguous(), 'item': g_item.contiguous()}
         g_out = {}
-        for t in _TYPES:
-            g_out[t] = (kernels.l2_normalize_bwd(self.z[t], g_emb[t], g_x=self.g_z[t]) if m.normalize == "l2"
-                        else g_emb[t])
+        self._side.wait_stream(main)
         for layer in range(L - 1, -1, -1):
             g_prev = self.g_h[layer - 1] if layer > 0 else None
             for t in _TYPES:
-                agg = m._aggs[layer][t]
-                rows = self.h[layer][t].shape[0]
-                out = self.z[t] if layer == L - 1 else self.h[layer][t]
-                x_self = self.x_self[t] if layer == 0 else self.h[layer - 1][t][:rows]
-                for p in agg.parameters():
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                kernels.sage_project_bwd(
-                    x_self, self.x_mean[layer][t][:rows], agg.w_self, agg.w_neigh, agg.activation, out, g_out[t],
-                    need_x_self=layer > 0, need_x_mean=layer > 0, need_bias=agg.bias is not None,
-                    g_w_self=agg.w_self.grad, g_w_neigh=agg.w_neigh.grad,
-                    g_bias=None if agg.bias is None else agg.bias.grad,
-                    g_x_self=self._g_self_dst(layer, t, g_prev) if layer > 0 else None,
-                    g_x_mean=self.g_xm[layer][t] if layer > 0 else None, workspace=self.ws[layer][t])
+                with torch.cuda.stream(streams[t]):
+                    if layer == L - 1:
+                        g_out[t] = (kernels.l2_normalize_bwd(self.z[t], g_emb[t], g_x=self.g_z[t])
+                                    if m.normalize == "l2" else g_emb[t])
+                    agg = m._aggs[layer][t]
+                    rows = self.h[layer][t].shape[0]
+                    out = self.z[t] if layer == L - 1 else self.h[layer][t]
+                    x_self = self.x_self[t] if layer == 0 else self.h[layer - 1][t][:rows]
+                    for p in agg.parameters():
+                        if p.grad is None:
+                            p.grad = torch.zeros_like(p)
+                    kernels.sage_project_bwd(
+                        x_self, self.x_mean[layer][t][:rows], agg.w_self, agg.w_neigh, agg.activation, out, g_out[t],
+                        need_x_self=layer > 0, need_x_mean=layer > 0, need_bias=agg.bias is not None,
+                        g_w_self=agg.w_self.grad, g_w_neigh=agg.w_neigh.grad,
+                        g_bias=None if agg.bias is None else agg.bias.grad,
+                        g_x_self=self._g_self_dst(layer, t, g_prev) if layer > 0 else None,
+                        g_x_mean=self.g_xm[layer][t] if layer > 0 else None, workspace=self.ws[layer][t])
             if layer == 0:
                 break
+            # each type's neighbor-slot gradients come from the OTHER type's g_xm: the streams meet here
+            main.wait_stream(self._side)
+            self._side.wait_stream(main)
             # gradient of h[layer-1]: head contribution (prefix rows) and neighbor contribution
             # (every slot beyond the roots is the neighbor slot of the slot two below it)
             for t in _TYPES:
-                for (s, h, side, r0, n) in self.segments[t]:
-                    if h > L - layer:                      # slot not alive at layer-1's output
-                        continue
-                    dst = g_prev[t][r0:r0 + n]
-                    wrote = False
-                    if h >= 1:                             # neighbor slot of slot s-2 (other type)
-                        _, p0, pn = self.where[s - 2]
-                        kernels.gather_mean_bwd(self.g_xm[layer][other[t]][p0:p0 + pn], None, self.fanouts[h - 1], dst)
-                        wrote = True
-                    if h <= L - 1 - layer:                 # head slot at this layer: its own-row gradient
-                        if wrote:
-                            dst.add_(self.g_xs[layer][t][r0:r0 + n])
-                        elif self._g_self_dst(layer, t, g_prev) is self.g_xs[layer][t]:
-                            dst.copy_(self.g_xs[layer][t][r0:r0 + n])
-                        # else: the projection backward wrote the roots' rows in place
+                with torch.cuda.stream(streams[t]):
+                    for (s, h, side, r0, n) in self.segments[t]:
+                        if h > L - layer:                      # slot not alive at layer-1's output
+                            continue
+                        dst = g_prev[t][r0:r0 + n]
+                        wrote = False
+                        if h >= 1:                             # neighbor slot of slot s-2 (other type)
+                            _, p0, pn = self.where[s - 2]
+                            kernels.gather_mean_bwd(self.g_xm[layer][other[t]][p0:p0 + pn], None, self.fanouts[h - 1], dst)
+                            wrote = True
+                        if h <= L - 1 - layer:                 # head slot at this layer: its own-row gradient
+                            if wrote:
+                                dst.add_(self.g_xs[layer][t][r0:r0 + n])
+                            elif self._g_self_dst(layer, t, g_prev) is self.g_xs[layer][t]:
+                                dst.copy_(self.g_xs[layer][t][r0:r0 + n])
+                            # else: the projection backward wrote the roots' rows in place
             g_out = {t: g_prev[t] for t in _TYPES}
+        main.wait_stream(self._side)
