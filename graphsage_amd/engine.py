@@ -66,6 +66,7 @@ class SageForwardEngine:
         self.hops = [torch.empty((2 * b, s), dtype=torch.int32, device=device) for s in sizes[1:]]
         self.err_flag = torch.zeros(2, dtype=torch.int32, device=device)
         self._hop_ptrs = None
+        self._side = None            # second stream (overlaps one type's gathers with the other's projection)
         self.probes = None           # list to receive (start, end) events around the dominant launches
         self.seeds_buf = torch.zeros(2 * b, dtype=torch.int32, device=device)   # placeholder roots
         # the fused kernels implement the mean aggregator; 'max' runs gather + reduce + projection
@@ -109,40 +110,52 @@ class SageForwardEngine:
         """Layers 0..L-1 on the ids left by ``sample``; returns (user_emb, item_emb)."""
         m = self.model
         other = self.other
-        # layer 0: own rows of every alive slot, then neighbor means
+        # Layer 0: own rows of every alive slot, then per type the neighbor means and the projection.
+        # The means are bound by HBM and the wide projections by the matrix pipe, so the item
+        # type's means run on a second stream beside the user type's projection.
         for t in _TYPES:
             feat, off = self.tables[t]
             for (_, h, side, r0, n) in self.segments[t]:
                 kernels.gather_rows(feat, self._slot_ids(seeds, h, side), off, out=self.x_self[t][r0:r0 + n])
-        for t in _TYPES:
-            for (s, h, side, r0, n) in self.segments[t]:
-                dst = self.x_mean[0][t][r0:r0 + n]
-                if h + 1 < self.n_hops:
-                    _, c0, cn = self.where[s + 2]
-                    self._reduce(self.x_self[other[t]][c0:c0 + cn], None, n, self.fanouts[h], out=dst)
-                else:
-                    feat, off = self.tables[other[t]]
-                    if self.probes is not None:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                    self._reduce(feat, self._slot_ids(seeds, h + 1, side), n, self.fanouts[h], off, out=dst)
-                    if self.probes is not None:
-                        e1.record()
-                        self.probes.append((e0, e1))
-        for layer in range(self.n_hops):
-            if layer > 0:
-                for t in _TYPES:
-                    for (s, h, side, r0, n) in self.segments[t]:
-                        if h > self.n_hops - 1 - layer:
-                            continue
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        for t in _TYPES:                                   # 'user' first
+            with torch.cuda.stream(main if t == 'user' else self._side):
+                for (s, h, side, r0, n) in self.segments[t]:
+                    dst = self.x_mean[0][t][r0:r0 + n]
+                    if h + 1 < self.n_hops:
                         _, c0, cn = self.where[s + 2]
-                        self._reduce(self.h[layer - 1][other[t]][c0:c0 + cn], None, n, self.fanouts[h],
-                                            out=self.x_mean[layer][t][r0:r0 + n])
+                        self._reduce(self.x_self[other[t]][c0:c0 + cn], None, n, self.fanouts[h], out=dst)
+                    else:
+                        feat, off = self.tables[other[t]]
+                        probe = self.probes is not None and t == 'user'      # the launch that runs alone
+                        if probe:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                        self._reduce(feat, self._slot_ids(seeds, h + 1, side), n, self.fanouts[h], off, out=dst)
+                        if probe:
+                            e1.record()
+                            self.probes.append((e0, e1))
+                if t == 'user':
+                    self._side.wait_stream(main)           # the side stream starts once these means are done
+                agg = m._aggs[0][t]
+                rows = self.h[0][t].shape[0]
+                kernels.sage_project(self.x_self[t][:rows], self.x_mean[0][t][:rows], agg.w_self, agg.w_neigh,
+                                     agg.bias, agg.activation, out=self.h[0][t])
+        main.wait_stream(self._side)
+        for layer in range(1, self.n_hops):
+            for t in _TYPES:
+                for (s, h, side, r0, n) in self.segments[t]:
+                    if h > self.n_hops - 1 - layer:
+                        continue
+                    _, c0, cn = self.where[s + 2]
+                    self._reduce(self.h[layer - 1][other[t]][c0:c0 + cn], None, n, self.fanouts[h],
+                                 out=self.x_mean[layer][t][r0:r0 + n])
             for t in _TYPES:
                 agg = m._aggs[layer][t]
                 rows = self.h[layer][t].shape[0]
-                x_self = self.x_self[t] if layer == 0 else self.h[layer - 1][t]
-                kernels.sage_project(x_self[:rows], self.x_mean[layer][t][:rows], agg.w_self, agg.w_neigh,
+                kernels.sage_project(self.h[layer - 1][t][:rows], self.x_mean[layer][t][:rows], agg.w_self, agg.w_neigh,
                                      agg.bias, agg.activation, out=self.h[layer][t])
         for t in _TYPES:
             if m.normalize == "l2":
