@@ -465,21 +465,6 @@ void sage2_kernel(const Sage2Args a) {
     float *w1n = w1s + H1 * HH2;
     float *bias = w1n + H1 * HH2;            // b0_u[H1] b0_i[H1] b1[H2]
     float *wave0 = bias + 2 * H1 + H2;
-    stage_weight(w0s_u, a.w0_self[0], FU, HH1);
-    stage_weight(w0n_u, a.w0_neigh[0], FI, HH1);
-    stage_weight(w0s_i, a.w0_self[1], FI, HH1);
-    stage_weight(w0n_i, a.w0_neigh[1], FU, HH1);
-    stage_weight(w1s, a.w1_self[side], H1, HH2);
-    stage_weight(w1n, a.w1_neigh[side], H1, HH2);
-    for (int i = threadIdx.x; i < 2 * H1 + H2; i += blockDim.x) {
-        float v = 0.f;
-        if (i < H1) { if (a.b0[0]) v = a.b0[0][i]; }
-        else if (i < 2 * H1) { if (a.b0[1]) v = a.b0[1][i - H1]; }
-        else { if (a.b1[side]) v = a.b1[side][i - 2 * H1]; }
-        bias[i] = v;
-    }
-    __syncthreads();
-
     // the wave index as a scalar: everything derived from it (walk number, root, LDS bases, output
     // rows) then lives in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -496,10 +481,28 @@ void sage2_kernel(const Sage2Args a) {
         return (unsigned long long)(long long)v < (unsigned long long)a.n_nodes ? v : -1;
     };
     long long p = (long long)(blockIdx.x >> 1) * n_waves + wave;
-    if (p >= a.n_pairs) return;
-    // the root of the next walk and its CSR row bounds are fetched one walk ahead
-    int32_t root = load_root(p);
+    const bool has_work = p < a.n_pairs;
+    // the root of a walk and its CSR row bounds are fetched one walk ahead; for the first walk that
+    // is here, so the two dependent reads are in flight while the block stages the weights
+    int32_t root = has_work ? load_root(p) : -1;
     int64_t ra = a.indptr[root >= 0 ? root : 0], rb = a.indptr[(root >= 0 ? root : 0) + 1];
+
+    stage_weight(w0s_u, a.w0_self[0], FU, HH1);
+    stage_weight(w0n_u, a.w0_neigh[0], FI, HH1);
+    stage_weight(w0s_i, a.w0_self[1], FI, HH1);
+    stage_weight(w0n_i, a.w0_neigh[1], FU, HH1);
+    stage_weight(w1s, a.w1_self[side], H1, HH2);
+    stage_weight(w1n, a.w1_neigh[side], H1, HH2);
+    for (int i = threadIdx.x; i < 2 * H1 + H2; i += blockDim.x) {
+        float v = 0.f;
+        if (i < H1) { if (a.b0[0]) v = a.b0[0][i]; }
+        else if (i < 2 * H1) { if (a.b0[1]) v = a.b0[1][i - H1]; }
+        else { if (a.b1[side]) v = a.b1[side][i - 2 * H1]; }
+        bias[i] = v;
+    }
+    __syncthreads();
+    if (!has_work) return;
+
     for (; p < a.n_pairs; p += stride) {
         const long long pn = p + stride;
         const int32_t next_root = pn < a.n_pairs ? load_root(pn) : -1;
