@@ -190,7 +190,7 @@ def synthetic_ratings(users_path, movies_path, n_ratings=200_000, seed=0):
     m_ids, m_feat, _ = movie_features(read_dat(movies_path, encoding='iso-8859-1'))
     rng = np.random.default_rng(seed)
     mix = rng.standard_normal((u_feat.shape[1], m_feat.shape[1]))
-    pop = rng.zipf(1.3, size=len(m_ids)).astype(np.float64)
+    pop = rng.permutation(np.arange(1, len(m_ids) + 1, dtype=np.float64) ** -0.9)     # long-tailed popularity
     ui = rng.integers(0, len(u_ids), n_ratings)
     mi = rng.choice(len(m_ids), size=n_ratings, p=pop / pop.sum())
     score = np.einsum('nf,fg,ng->n', u_feat[ui], mix, m_feat[mi]) / np.sqrt(np.maximum(m_feat[mi].sum(1), 1.0))
