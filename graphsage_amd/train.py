@@ -148,6 +148,8 @@ class Trainer:
         self.bucket = FlatGradBucket(self.params)
         self.opt = Adam(self.params, self.bucket.flat, lr=lr, params_flat=self.bucket.flat_params)
         self._head_step = None
+        self._fwd_engine = None
+        self._graph_obj, self._batch_size = graph, batch_size
         self.group = group
         self.engine = None
         if engine in ('auto', 'plan') and graph is not None and batch_size is not None:
@@ -292,8 +294,9 @@ class Trainer:
                     planned = seeds.numel() == 2 * self.engine.batch
                 if planned:
                     y_dev = torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)
-                    loss, pred = self.step_device(seeds, y_dev, walk_ids, key)
-                    pred = pred.clone()
+                    # replayed HIP graph; loss and pred are its static outputs, consumed (in stream
+                    # order) by the metric updates below before the next replay overwrites them
+                    loss, pred = self.step_graph(seeds, y_dev, walk_ids, key)
                 else:
                     batch, y = train_seq[i]
                     y_dev = torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)
@@ -305,6 +308,7 @@ class Trainer:
                     m.update_state(y_dev, pred)
             logs = {'loss': float(loss_sum) / max(seen, 1)}
             logs.update({m.name: m.result() for m in mets})
+            self._raise_sampling_errors()
             if validation_data is not None:
                 logs.update({'val_' + k: v for k, v in self.evaluate(validation_data).items()})
             for k, v in logs.items():
@@ -314,6 +318,31 @@ class Trainer:
             train_seq.on_epoch_end()
         return history
 
+    def _raise_sampling_errors(self):
+        """The engines only flag a node without neighbors or an unknown root (the
+        reference raises for either while it builds the batch); surface the
+        flags as the same exceptions, once per pass over a sequence."""
+        from .sampler import BreadthFirstWalker
+        for eng in (self.engine, self._fwd_engine):
+            if eng is not None:
+                BreadthFirstWalker.raise_on_error(eng.err_flag)
+
+    @torch.no_grad()
+    def _scores(self, seq, i):
+        """(scores (b, 1), targets) of batch i: through the forward engine when the
+        batch is a full one of a keyed sequence, else through the model."""
+        if (self.engine is not None and getattr(seq, '_indexed', False) and hasattr(seq, 'roots')
+                and not (self.model.dropout and self.model.training)):
+            seeds, walk_ids, key, y = seq.roots(i)
+            if seeds.numel() == 2 * self.engine.batch:
+                if self._fwd_engine is None:
+                    from .engine import SageForwardEngine
+                    self._fwd_engine = SageForwardEngine(self._graph_obj, self.model, self._batch_size)
+                emb = self._fwd_engine.forward(seeds, walk_ids, rng_seed=key)
+                return self.head(emb), y
+        batch, y = seq[i]
+        return self.head(self.model(batch)), y
+
     @torch.no_grad()
     def evaluate(self, seq):
         """Loss and metrics of the current weights over a sequence (no update)."""
@@ -321,21 +350,22 @@ class Trainer:
         mets = self._metrics()
         loss_sum, seen = torch.zeros((), dtype=torch.float64, device=dev), 0
         for i in range(len(seq)):
-            batch, y = seq[i]
+            pred, y = self._scores(seq, i)
             y_dev = torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)
-            loss, pred = self.loss(batch, y_dev)
+            loss = ((pred - y_dev.reshape(pred.shape)) ** 2).mean()
             loss_sum += loss.double() * y_dev.numel()
             seen += y_dev.numel()
             for m in mets:
                 m.update_state(y_dev, pred)
         out = {'loss': float(loss_sum) / max(seen, 1)}
         out.update({m.name: m.result() for m in mets})
+        self._raise_sampling_errors()
         return out
 
     @torch.no_grad()
     def predict(self, seq):
         """Scores of every link of a sequence, in sequence order: float32 [n, 1]."""
-        return torch.cat([self.head(self.model(seq[i][0])) for i in range(len(seq))])
+        return torch.cat([self._scores(seq, i)[0] for i in range(len(seq))])
 
     def step(self, batch, targets):
         self.bucket.zero()

@@ -257,3 +257,29 @@ def test_movielens_format_fit_learns_and_both_step_paths_agree(cuda, tmp_path):
     assert abs(ev['auc'] - h_plan['val_auc'][-1]) < 1e-9
     with pytest.raises(NotImplementedError):
         link_classification(edge_embedding_method='ip')
+
+
+def test_fit_surfaces_a_node_without_neighbors_like_the_reference(cuda):
+    """Node 2 (a user) has no edge: the reference raises while it builds the batch
+    (sampler.py:81-82 / bipartite_graph.py:63); the planned path flags it in the
+    kernel and fit raises after the pass."""
+    rng = np.random.default_rng(0)
+    nu, ni = 40, 10
+    u = np.concatenate([np.arange(nu), rng.integers(0, nu, 300)])
+    u = u[u != 2]
+    it = rng.integers(0, ni, u.size) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, 32)).astype(np.float32),
+             'item': rng.standard_normal((ni, 32)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))}, np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, 8, [3, 2], head_node_types=['user', 'item'], seed=1)
+    links = [(int(a), int(b)) for a, b in zip(u[:15], it[:15])] + [(2, nu)]
+    seq = gen.flow(links, targets=np.ones(16, np.float32))
+    model = ga.GraphSAGE([32, 32], gen, seed=2)
+    tr = Trainer(model, lr=1e-2, graph=g, batch_size=8)
+    assert tr.engine is not None
+    with pytest.raises(ValueError) as ei:
+        tr.fit(seq, epochs=1, verbose=0)
+    assert str(ei.value).startswith("Samples must exist. Self-node also can be a sample")
+    with pytest.raises(KeyError):                      # the same error is a KeyError too, as the dict lookup gives
+        tr.evaluate(seq)
