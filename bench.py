@@ -34,6 +34,9 @@ WORKLOADS = {
     'cfg5': dict(nu=1_000_000, ni=100_000, e=50_000_000, fu=256, fi=256, fan=[25, 10, 5], layers=[256, 256, 256],
                  alpha_item=1.1, alpha_user=None,
                  desc="cfg2 graph, 3-hop [25,10,5], 256-d features, 256 hidden"),
+    'cfg2h3': dict(nu=1_000_000, ni=100_000, e=50_000_000, fu=64, fi=64, fan=[25, 10, 5], layers=[32, 32, 32],
+                   alpha_item=1.1, alpha_user=None,
+                   desc="cfg2 graph and widths, 3-hop [25,10,5] (layered path: sampler + one fused kernel per layer and type)"),
     'ml1m': dict(nu=6040, ni=3706, e=226_310, fu=24, fi=19, fan=[10, 5], layers=[32, 32],
                  alpha_item=0.9, alpha_user=None,
                  desc="MovieLens-1M-shaped synthetic 6040 x 3706, 226k edges, 2-hop [10,5]"),
@@ -211,9 +214,9 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0                       # this rank's K steps; the slowest rank counts (MAX below)
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
     engine.probes = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=sync_dev)
@@ -270,9 +273,9 @@ def main():
             for i in range(args.train_steps):
                 tstep(5 + i)
             torch.cuda.synchronize()
+            t_el = time.perf_counter() - t1
             if world > 1:
                 dist.barrier()
-            t_el = time.perf_counter() - t1
             if world > 1:
                 tt = torch.tensor([t_el], dtype=torch.float64, device=sync_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
