@@ -243,7 +243,10 @@ class Trainer:
                 self.opt.v.copy_(v_save)
             torch.cuda.current_stream().wait_stream(side)
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            # thread-local capture checks: a communicator's watchdog thread may poll its own events
+            # while this thread captures
+            torch.cuda.synchronize()
+            with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
                 self._graph_body(not multi)
         eng.seeds_buf.copy_(seeds)
         self._walk_buf.copy_(walk_ids)
