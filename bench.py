@@ -142,7 +142,7 @@ def result_line(args, cfg, engine, world, b, fwd, train, cpu):
         "achieved_hbm_gbps_whole_step": (samp_bytes + agg_bytes) / b * value / world / 1e9,
         "roofline": {"bound": "hbm", "kernel": engine.dominant_name(), "achieved": achieved, "peak": 8000.0,
                      "unit": "GB/s", "frac": achieved / 8000.0, "traffic": engine.measured_traffic(args.workload),
-                     "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes},
+                     "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes, "launches_timed": len(dom_ms)},
     }
     if train is not None:
         out["train_step"] = train
@@ -205,13 +205,15 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    # HIP events around the dominant kernel of every fifth step of the timed region (an event pair
+    # costs several microseconds of queue time, which every step would otherwise pay)
     probes = []
-    engine.probes = probes
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        engine.probes = probes if i % 5 == 0 else None
         step(args.warmup + i)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0                       # this rank's K steps; the slowest rank counts (MAX below)
