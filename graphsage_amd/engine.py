@@ -7,6 +7,13 @@ layer is ONE projection launch per type, and a step is a fixed list of kernel
 launches on the current stream with no host synchronisation (it can be captured
 in a HIP graph).  It is what the benchmark times and what inference uses.
 
+Three routes, picked at construction: two hops with supported widths run as ONE
+kernel (``gs_sage2_forward``, one wavefront per walk); other depths with
+supported widths as the sampler kernel plus one fused kernel per (layer, node
+type); everything else (any width, the max aggregator) as sampler + gathers +
+projections, with the item type's gather-means on a second stream beside the
+user type's projection.
+
 Buffer layout.  Slot ``s = 2*h + side`` (hop ``h`` of the walks rooted at head
 ``side``) has ``B * P_h`` nodes of type ``TYPES[(side + h) % 2]``.  Per node
 type ``T`` the head rows of all alive slots of that type are stored back to
