@@ -32,6 +32,8 @@ SIGNATURES = {
     'gs_group_max_bwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     'gs_gather_mean_bwd': (_i32, [_vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _vp]),
     'gs_sage_project_fwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'gs_sage_project_gather_fwd': (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32,
+                                          _vp, _vp]),
     'gs_sage_project_bwd_workspace': (_sz, [_i32, _i32, _i32, _i64]),
     'gs_sage_project_bwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

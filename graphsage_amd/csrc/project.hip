@@ -45,7 +45,18 @@ struct GemmSide {
     int lda, K, N, ldbk, ldbn, ldo;
     int vec;             // 16-byte loads of A rows are legal
     int ncb;             // 64-column blocks of this side
+    // optional indirection: row m of A is row (row_ids[m] - id_off) of the table A points to
+    // (n_table rows); an id outside the table contributes a row of zeros
+    const int32_t *row_ids;
+    long long id_off, n_table;
 };
+
+// table row of logical row m (or -1: a row of zeros)
+__device__ __forceinline__ int64_t gemm_src_row(const int32_t *row_ids, long long id_off, long long n_table, int64_t m) {
+    if (!row_ids) return m;
+    const int64_t r = (int64_t)row_ids[m] - id_off;
+    return (uint64_t)r < (uint64_t)n_table ? r : -1;
+}
 
 __global__ __launch_bounds__(kThreads)
 void rows_gemm_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
@@ -62,6 +73,8 @@ void rows_gemm_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     float *__restrict__ outp = GS_SEL(out);
     const int K = GS_SEL(K), N = GS_SEL(N), lda = GS_SEL(lda);
     const int ldbk = GS_SEL(ldbk), ldbn = GS_SEL(ldbn), ldo = GS_SEL(ldo), vec = GS_SEL(vec);
+    const int32_t *__restrict__ row_ids = GS_SEL(row_ids);
+    const long long id_off = GS_SEL(id_off), n_table = GS_SEL(n_table);
 #undef GS_SEL
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int tid = threadIdx.x;
@@ -83,13 +96,14 @@ void rows_gemm_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
             const int64_t grow = row0 + row;
             const int k = k0 + kq;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (grow < M) {
-                const float *src = A + grow * lda + k;
+            const int64_t srow = grow < M ? gemm_src_row(row_ids, id_off, n_table, grow) : -1;
+            if (srow >= 0) {
+                const float *src = A + srow * lda + k;
                 if (vec && k + 3 < K) {
                     const float4 t = *reinterpret_cast<const float4 *>(src);
                     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
                     if (Mk) {
-                        const float4 m = *reinterpret_cast<const float4 *>(Mk + grow * lda + k);
+                        const float4 m = *reinterpret_cast<const float4 *>(Mk + srow * lda + k);
                         if (!(m.x > 0.f)) v[0] = 0.f;
                         if (!(m.y > 0.f)) v[1] = 0.f;
                         if (!(m.z > 0.f)) v[2] = 0.f;
@@ -100,7 +114,7 @@ void rows_gemm_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
                     for (int i = 0; i < 4; ++i) {
                         if (k + i < K) {
                             v[i] = src[i];
-                            if (Mk && !(Mk[grow * lda + k + i] > 0.f)) v[i] = 0.f;
+                            if (Mk && !(Mk[srow * lda + k + i] > 0.f)) v[i] = 0.f;
                         }
                     }
                 }
@@ -191,6 +205,8 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     const float *__restrict__ bias = GS_SEL(bias);
     float *__restrict__ outp = GS_SEL(out);
     const int K = GS_SEL(K), lda = GS_SEL(lda), ldbk = GS_SEL(ldbk), ldo = GS_SEL(ldo);
+    const int32_t *__restrict__ row_ids = GS_SEL(row_ids);
+    const long long id_off = GS_SEL(id_off), n_table = GS_SEL(n_table);
 #undef GS_SEL
     const int64_t row0 = (int64_t)blockIdx.x * GB_M;
     const int tid = threadIdx.x;
@@ -200,13 +216,16 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     // staging roles.  A: GB_KQ lanes cover one row's slice (16 bytes each), 256/GB_KQ rows per pass.
     const int a_kq = tid % GB_KQ;
     const float *a_src[GB_NP];
+    bool a_zero[GB_NP];
     int a_dst[GB_NP];
 #pragma unroll
     for (int p = 0; p < GB_NP; ++p) {
         const int row = p * (kThreads / GB_KQ) + tid / GB_KQ;
         int64_t grow = row0 + row;
         if (grow > M - 1) grow = M - 1;                 // rows past the end repeat the last one; never stored
-        a_src[p] = A + grow * lda + a_kq * 4;
+        const int64_t srow = gemm_src_row(row_ids, id_off, n_table, grow);
+        a_zero[p] = srow < 0;                           // an id outside the table: the row counts as zeros
+        a_src[p] = A + (srow < 0 ? 0 : srow) * lda + a_kq * 4;
         // within a fragment block the 16 slots of a lane quarter are rotated by GB_NR * (k quad): the
         // 16-lane groups of this write (GB_NR rows x GB_KQ k quads) and of the fragment read (sixteen
         // rows of one quad) then both touch sixteen different 16-byte bank groups
@@ -248,6 +267,12 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
         if constexpr (GB_NP == 4) {                                                                \
             ar2 = *reinterpret_cast<const float4 *>(a_src[GB_NP - 2] + k0);                        \
             ar3 = *reinterpret_cast<const float4 *>(a_src[GB_NP - 1] + k0);                        \
+        }                                                                                          \
+        if (row_ids) {                                                                             \
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+            if (a_zero[0]) ar0 = z4;                                                               \
+            if (a_zero[1]) ar1 = z4;                                                               \
+            if constexpr (GB_NP == 4) { if (a_zero[GB_NP - 2]) ar2 = z4; if (a_zero[GB_NP - 1]) ar3 = z4; } \
         }                                                                                          \
         GB_LOAD_B(br0, 0, k0) GB_LOAD_B(br1, 1, k0)                                                \
         if constexpr (GB_NP == 4) { GB_LOAD_B(br2, GB_NP - 2, k0) GB_LOAD_B(br3, GB_NP - 1, k0) }  \
@@ -738,9 +763,11 @@ inline void wgrad_chunks(int64_t M, int64_t *rows_per_chunk, int64_t *n_chunks) 
 
 }  // namespace
 
-extern "C" int gs_sage_project_fwd(const float *x_self, int Fs, const float *x_mean, int Fn, int64_t M,
-                                   const float *W_self, const float *W_neigh, const float *bias,
-                                   int H, int act, float *out, void *stream) {
+namespace {
+
+int project_fwd(const float *x_self, const int32_t *self_ids, int64_t off_self, int64_t n_rows_self, int Fs,
+                const float *x_mean, int Fn, int64_t M, const float *W_self, const float *W_neigh,
+                const float *bias, int H, int act, float *out, void *stream) {
     if (int rc = check_project_shape("gs_sage_project_fwd", Fs, Fn, M, H, act)) return rc;
     if (M == 0) return GS_OK;
     if (!x_self || !x_mean || !W_self || !W_neigh || !out)
@@ -750,6 +777,7 @@ extern "C" int gs_sage_project_fwd(const float *x_self, int Fs, const float *x_m
     s0.A = x_self; s0.B = W_self; s0.bias = bias; s0.out = out;
     s0.lda = Fs; s0.K = Fs; s0.N = Hh; s0.ldbk = Hh; s0.ldbn = 1; s0.ldo = H;
     s0.vec = Fs % 4 == 0 && aligned16(x_self); s0.ncb = (Hh + BN - 1) / BN;
+    s0.row_ids = self_ids; s0.id_off = off_self; s0.n_table = n_rows_self;
     s1.A = x_mean; s1.B = W_neigh; s1.bias = bias ? bias + Hh : nullptr; s1.out = out + Hh;
     s1.lda = Fn; s1.K = Fn; s1.N = Hh; s1.ldbk = Hh; s1.ldbn = 1; s1.ldo = H;
     s1.vec = Fn % 4 == 0 && aligned16(x_mean); s1.ncb = s0.ncb;
@@ -769,6 +797,24 @@ extern "C" int gs_sage_project_fwd(const float *x_self, int Fs, const float *x_m
     hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)bx, (unsigned)by), dim3(kThreads), 0, (hipStream_t)stream,
                        s0, s1, M, act);
     return gs::check_launch("gs_sage_project_fwd");
+}
+
+}  // namespace
+
+extern "C" int gs_sage_project_fwd(const float *x_self, int Fs, const float *x_mean, int Fn, int64_t M,
+                                   const float *W_self, const float *W_neigh, const float *bias,
+                                   int H, int act, float *out, void *stream) {
+    return project_fwd(x_self, nullptr, 0, 0, Fs, x_mean, Fn, M, W_self, W_neigh, bias, H, act, out, stream);
+}
+
+extern "C" int gs_sage_project_gather_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
+                                          const int32_t *self_ids, const float *x_mean, int Fn, int64_t M,
+                                          const float *W_self, const float *W_neigh, const float *bias,
+                                          int H, int act, float *out, void *stream) {
+    if (M > 0 && !self_ids) return gs::fail(GS_EINVAL, "gs_sage_project_gather_fwd: null pointer argument");
+    if (n_rows_self < 0) return gs::fail(GS_EINVAL, "gs_sage_project_gather_fwd: n_rows_self=%lld", (long long)n_rows_self);
+    return project_fwd(feat_self, self_ids, off_self, n_rows_self, Fs, x_mean, Fn, M, W_self, W_neigh, bias, H, act,
+                       out, stream);
 }
 
 extern "C" size_t gs_sage_project_bwd_workspace(int Fs, int Fn, int H, int64_t M) {

@@ -117,39 +117,35 @@ class SageForwardEngine:
         """Layers 0..L-1 on the ids left by ``sample``; returns (user_emb, item_emb)."""
         m = self.model
         other = self.other
-        # Layer 0: own rows of every alive slot, then per type the neighbor means and the projection.
-        # The means are bound by HBM and the wide projections by the matrix pipe, so the item
-        # type's means run on a second stream beside the user type's projection.
-        for t in _TYPES:
-            feat, off = self.tables[t]
-            for (_, h, side, r0, n) in self.segments[t]:
-                kernels.gather_rows(feat, self._slot_ids(seeds, h, side), off, out=self.x_self[t][r0:r0 + n])
+        # Layer 0, per type: the neighbor means of every alive slot (children rows summed as they
+        # are fetched from the other type's table), then the projection, which reads the own rows
+        # from the table by id -- no gathered copy of either is written.  The means are bound by
+        # HBM and the wide projections by the matrix pipe, so the item type's means run on a
+        # second stream beside the user type's projection.
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
         for t in _TYPES:                                   # 'user' first
             with torch.cuda.stream(main if t == 'user' else self._side):
+                feat_o, off_o = self.tables[other[t]]
                 for (s, h, side, r0, n) in self.segments[t]:
                     dst = self.x_mean[0][t][r0:r0 + n]
-                    if h + 1 < self.n_hops:
-                        _, c0, cn = self.where[s + 2]
-                        self._reduce(self.x_self[other[t]][c0:c0 + cn], None, n, self.fanouts[h], out=dst)
-                    else:
-                        feat, off = self.tables[other[t]]
-                        probe = self.probes is not None and t == 'user'      # the launch that runs alone
-                        if probe:
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                        self._reduce(feat, self._slot_ids(seeds, h + 1, side), n, self.fanouts[h], off, out=dst)
-                        if probe:
-                            e1.record()
-                            self.probes.append((e0, e1))
+                    probe = self.probes is not None and t == 'user' and h + 1 == self.n_hops   # runs alone
+                    if probe:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    self._reduce(feat_o, self._slot_ids(seeds, h + 1, side), n, self.fanouts[h], off_o, out=dst)
+                    if probe:
+                        e1.record()
+                        self.probes.append((e0, e1))
                 if t == 'user':
                     self._side.wait_stream(main)           # the side stream starts once these means are done
                 agg = m._aggs[0][t]
-                rows = self.h[0][t].shape[0]
-                kernels.sage_project(self.x_self[t][:rows], self.x_mean[0][t][:rows], agg.w_self, agg.w_neigh,
-                                     agg.bias, agg.activation, out=self.h[0][t])
+                feat, off = self.tables[t]
+                for (s, h, side, r0, n) in self.segments[t]:
+                    kernels.sage_project_gather(feat, self._slot_ids(seeds, h, side), off, self.x_mean[0][t][r0:r0 + n],
+                                                agg.w_self, agg.w_neigh, agg.bias, agg.activation,
+                                                out=self.h[0][t][r0:r0 + n])
         main.wait_stream(self._side)
         for layer in range(1, self.n_hops):
             for t in _TYPES:

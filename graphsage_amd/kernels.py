@@ -213,6 +213,38 @@ def sage_project(x_self, x_mean, w_self, w_neigh, bias, act, out=None):
     return out
 
 
+def sage_project_gather(feat_self, self_ids, id_offset, x_mean, w_self, w_neigh, bias, act, out=None):
+    """sage_project with the own rows read from the feature table ``feat_self`` by
+    node id (``self_ids`` int32[M], table row = id - id_offset) inside the kernel."""
+    lib = load()
+    _dev(feat_self, torch.float32, 'feat_self', 2)
+    _dev(self_ids, torch.int32, 'self_ids', 1)
+    _dev(x_mean, torch.float32, 'x_mean', 2)
+    _dev(w_self, torch.float32, 'w_self', 2)
+    _dev(w_neigh, torch.float32, 'w_neigh', 2)
+    m, fs, fn, hh = self_ids.numel(), feat_self.shape[1], x_mean.shape[1], w_self.shape[1]
+    if x_mean.shape[0] != m:
+        raise ValueError("self_ids and x_mean must have the same number of rows")
+    if w_self.shape[0] != fs or w_neigh.shape != (fn, hh):
+        raise ValueError("weight shapes %s / %s do not match inputs (%d, %d)" %
+                         (tuple(w_self.shape), tuple(w_neigh.shape), fs, fn))
+    if bias is not None:
+        _dev(bias, torch.float32, 'bias', 1)
+        if bias.numel() != 2 * hh:
+            raise ValueError("bias must have %d entries" % (2 * hh))
+    h = 2 * hh
+    if out is None:
+        out = torch.empty((m, h), dtype=torch.float32, device=x_mean.device)
+    else:
+        _dev(out, torch.float32, 'out')
+        if out.numel() != m * h:
+            raise ValueError("out has %d elements, %d needed" % (out.numel(), m * h))
+    check(lib.gs_sage_project_gather_fwd(ptr(feat_self), feat_self.shape[0], fs, int(id_offset), ptr(self_ids),
+                                         ptr(x_mean), fn, m, ptr(w_self), ptr(w_neigh), ptr(bias), h, ACT[act],
+                                         ptr(out), stream_handle()), 'gs_sage_project_gather_fwd')
+    return out
+
+
 def sage_project_bwd(x_self, x_mean, w_self, w_neigh, act, out, g_out, need_x_self=True, need_x_mean=True,
                      need_bias=True, g_w_self=None, g_w_neigh=None, g_bias=None, g_x_self=None, g_x_mean=None,
                      workspace=None):

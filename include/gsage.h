@@ -170,6 +170,18 @@ int gs_sage_project_fwd(const float *x_self, int Fs, const float *x_mean, int Fn
                         int H, int act, float *out, void *stream);
 
 /*
+ * The same with the own rows taken from a feature table by node id while the
+ * product is formed: x_self[m, :] = feat_self[self_ids[m] - off_self, :] (an id
+ * outside the table counts as a row of zeros), so the gathered copy of
+ * Graph.get_node_features_from_node (bipartite_graph.py:70-76, generator.py:
+ * 270-277) is never written.  self_ids device int32[M].
+ */
+int gs_sage_project_gather_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
+                               const int32_t *self_ids, const float *x_mean, int Fn, int64_t M,
+                               const float *W_self, const float *W_neigh, const float *bias,
+                               int H, int act, float *out, void *stream);
+
+/*
  * Backward of gs_sage_project_fwd.  `out` is the forward result (needed for the
  * relu mask), g_out its gradient.  Any of the g_* outputs may be NULL to skip
  * it.  g_W_self / g_W_neigh / g_bias are overwritten (not accumulated).

@@ -716,3 +716,27 @@ def test_engine_runs_the_max_aggregator_through_the_general_kernels(cuda):
     from graphsage_amd.train_engine import SageTrainEngine
     with pytest.raises(Exception):
         SageTrainEngine(g, model, b)
+
+
+@pytest.mark.parametrize('m,fs,fn,h', [(300, 64, 64, 32), (77, 24, 19, 32), (700, 256, 256, 256), (1100, 64, 128, 256)])
+def test_projection_with_own_rows_gathered_in_the_kernel(cuda, m, fs, fn, h):
+    """gs_sage_project_gather_fwd == gs_gather_rows followed by gs_sage_project_fwd,
+    bit for bit (same kernel arithmetic), including ids outside the table (zero rows)."""
+    rng = np.random.default_rng(m + fs)
+    n_rows, off = 5000, 1234
+    feat = torch.from_numpy(rng.standard_normal((n_rows, fs)).astype(np.float32)).to(cuda)
+    ids = rng.integers(0, n_rows, m).astype(np.int32) + off
+    ids[3], ids[m - 1] = off - 1, off + n_rows                       # just outside, both ends
+    ids_t = torch.from_numpy(ids).to(cuda)
+    x_mean = torch.from_numpy(rng.standard_normal((m, fn)).astype(np.float32)).to(cuda)
+    ws = torch.from_numpy((rng.standard_normal((fs, h // 2)) * 0.1).astype(np.float32)).to(cuda)
+    wn = torch.from_numpy((rng.standard_normal((fn, h // 2)) * 0.1).astype(np.float32)).to(cuda)
+    b = torch.from_numpy(rng.standard_normal(h).astype(np.float32)).to(cuda)
+    for act in ('relu', 'linear'):
+        got = kernels.sage_project_gather(feat, ids_t, off, x_mean, ws, wn, b, act)
+        x_self = kernels.gather_rows(feat, ids_t, off)
+        assert float(x_self[3].abs().max()) == 0.0 and float(x_self[m - 1].abs().max()) == 0.0
+        want = kernels.sage_project(x_self, x_mean, ws, wn, b, act)
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        kernels.sage_project_gather(feat, ids_t[:-1].contiguous(), off, x_mean, ws, wn, b, 'relu')
