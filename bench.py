@@ -205,8 +205,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    # HIP events around the dominant kernel of every fifth step of the timed region (an event pair
-    # costs several microseconds of queue time, which every step would otherwise pay)
+    # the dominant kernel of every fifth step of the timed region is launched with a pair of HIP
+    # events in its own dispatch packet (exact start/end of that kernel on its stream)
     probes = []
     if world > 1:
         dist.barrier()
@@ -227,7 +227,7 @@ def main():
     err = engine.err_flag.tolist()
     assert err == [0, 0], "sampler reported %s" % err
 
-    fwd = {"elapsed": elapsed, "probes": [a.elapsed_time(c) for a, c in probes]}
+    fwd = {"elapsed": elapsed, "probes": [t.elapsed_us() * 1e-3 for t in probes]}        # milliseconds
 
     # secondary: the training step (sample + forward + backward + gradient all-reduce + Adam).
     # It must never cost the headline number: if it stalls (a collective that never returns),

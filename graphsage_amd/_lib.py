@@ -22,6 +22,10 @@ _vp, _i32, _i64, _u64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.
 SIGNATURES = {
     'gs_version': (_i32, []),
     'gs_last_error': (_c.c_char_p, []),
+    'gs_timer_create': (_i32, [_c.POINTER(_vp)]),
+    'gs_timer_arm': (_i32, [_vp]),
+    'gs_timer_elapsed_us': (_i32, [_vp, _c.POINTER(_c.c_float)]),
+    'gs_timer_destroy': (_i32, [_vp]),
     'gs_sample': (_i32, [_vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32), _i32, _u64, _u64, _vp, _vp,
                          _c.POINTER(_vp), _vp, _vp]),
     'gs_csr_build_workspace': (_i32, [_i64, _i64, _i64, _c.POINTER(_sz)]),

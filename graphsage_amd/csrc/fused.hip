@@ -284,9 +284,9 @@ int launch(const FusedArgs &a, hipStream_t stream) {
     const long long cap = 256 * 8;                      // a few blocks per CU; waves loop over tiles
     if (blocks > cap) blocks = cap;
     if (a.seg[0].child_ids)
-        hipLaunchKernelGGL((sage_fused_kernel<FS, FN, HH, false>), dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
+        gs::launch_timed(sage_fused_kernel<FS, FN, HH, false>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
     else
-        hipLaunchKernelGGL((sage_fused_kernel<FS, FN, HH, true>), dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
+        gs::launch_timed(sage_fused_kernel<FS, FN, HH, true>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
     return gs::check_launch("gs_sage_fused_fwd");
 }
 

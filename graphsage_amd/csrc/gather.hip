@@ -235,9 +235,9 @@ int gather_reduce_fwd(const char *what, const float *feat, int64_t n_rows, int F
     const size_t lds = stage ? (size_t)tile * n_child * sizeof(int32_t) : 0;
     const unsigned grid = grid_for(n_parents, tile);
     hipStream_t s = (hipStream_t)stream;
-    if (vec == 4) hipLaunchKernelGGL((gather_mean_kernel<4, MAXOP>), dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
-    else if (vec == 2) hipLaunchKernelGGL((gather_mean_kernel<2, MAXOP>), dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
-    else hipLaunchKernelGGL((gather_mean_kernel<1, MAXOP>), dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
+    if (vec == 4) gs::launch_timed(gather_mean_kernel<4, MAXOP>, dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
+    else if (vec == 2) gs::launch_timed(gather_mean_kernel<2, MAXOP>, dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
+    else gs::launch_timed(gather_mean_kernel<1, MAXOP>, dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
     return gs::check_launch(what);
 }
 

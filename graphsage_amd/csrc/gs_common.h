@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -19,6 +20,23 @@ inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GS_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
     return GS_OK;
+}
+
+// A pair of events armed by gs_timer_arm(): the next timed launch of this thread is bracketed by
+// them exactly (start and stop are stamped by the kernel's own dispatch packet, with no marker
+// packets in between), then the pair is disarmed.
+struct LaunchTimer {
+    hipEvent_t start, stop;
+};
+LaunchTimer *take_armed_timer();            // NULL when none is armed
+
+// Launch of a kernel that a benchmark may want to time: plain launch unless a timer is armed.
+template <class K, class... Args>
+inline void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+    if (LaunchTimer *t = take_armed_timer())
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, t->start, t->stop, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
 }
 
 constexpr int kWave = 64;

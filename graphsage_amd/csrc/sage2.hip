@@ -533,7 +533,7 @@ int launch_one(const Sage2Args &a, hipStream_t stream) {
     }
     long long blocks = 2 * ((a.n_pairs + waves - 1) / waves);   // even blocks: user roots, odd: item roots
     if (blocks > 256) blocks = 256;                      // one block per CU, waves loop over walks
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, a);
+    gs::launch_timed(kern, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, a);
     return gs::check_launch("gs_sage2_forward");
 }
 

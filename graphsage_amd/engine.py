@@ -74,7 +74,7 @@ class SageForwardEngine:
         self.err_flag = torch.zeros(2, dtype=torch.int32, device=device)
         self._hop_ptrs = None
         self._side = None            # second stream (overlaps one type's gathers with the other's projection)
-        self.probes = None           # list to receive (start, end) events around the dominant launches
+        self.probes = None           # list to receive the LaunchTimers of the dominant launches
         self.seeds_buf = torch.zeros(2 * b, dtype=torch.int32, device=device)   # placeholder roots
         # the fused kernels implement the mean aggregator; 'max' runs gather + reduce + projection
         self.agg_max = getattr(model, 'agg_option', 'mean') == 'max'
@@ -88,6 +88,14 @@ class SageForwardEngine:
             f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'], *self.fanouts))
         self._walk_call = None
         self.emb_all = torch.empty((2 * b, model.dims[-1]['user']), dtype=torch.float32, device=device)
+
+    def _arm_probe(self):
+        """The next dominant-kernel launch carries a pair of HIP events in its own
+        dispatch (exact start and end, nothing extra enqueued); the timer joins
+        ``self.probes`` and is read with ``elapsed_us()`` after the run."""
+        t = kernels.LaunchTimer()
+        t.arm()
+        self.probes.append(t)
 
     # -- pieces ---------------------------------------------------------------
     def _slot_ids(self, seeds, h, side):
@@ -132,12 +140,8 @@ class SageForwardEngine:
                     dst = self.x_mean[0][t][r0:r0 + n]
                     probe = self.probes is not None and t == 'user' and h + 1 == self.n_hops   # runs alone
                     if probe:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
+                        self._arm_probe()
                     self._reduce(feat_o, self._slot_ids(seeds, h + 1, side), n, self.fanouts[h], off_o, out=dst)
-                    if probe:
-                        e1.record()
-                        self.probes.append((e0, e1))
                 if t == 'user':
                     self._side.wait_stream(main)           # the side stream starts once these means are done
                 agg = m._aggs[0][t]
@@ -215,13 +219,8 @@ class SageForwardEngine:
                     if h == 0:
                         call.set_head_ids(i, self._slot_ids(seeds, 0, side))
             if self.probes is not None and layer == 0:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                call.run()
-                e1.record()
-                self.probes.append((e0, e1))
-            else:
-                call.run()
+                self._arm_probe()
+            call.run()
 
     def aggregate_fused(self, seeds):
         """Same result as ``aggregate`` with one kernel per (layer, node type)."""
@@ -241,12 +240,8 @@ class SageForwardEngine:
                                                 self.tables['item'][0], self.fanouts, weights,
                                                 m.normalize == "l2", self.batch, emb=self.emb_all)
         if self.probes is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            self._arm_probe()
         self._walk_call.run(seeds, self.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
-        if self.probes is not None:
-            e1.record()
-            self.probes.append((e0, e1))
         return self.emb_all[:self.batch], self.emb_all[self.batch:]
 
     def forward(self, seeds, walk_ids=None, rng_seed=0, replay=None):

@@ -27,6 +27,31 @@ def _dev(t, dtype, name, ndim=None):
     return t
 
 
+class LaunchTimer:
+    """Exact duration of one kernel launch (``gs_timer_*``): ``arm()`` right before
+    the call whose main kernel is to be timed, ``elapsed_us()`` afterwards."""
+
+    def __init__(self):
+        self._lib = load()
+        h = ctypes.c_void_p()
+        check(self._lib.gs_timer_create(ctypes.byref(h)), 'gs_timer_create')
+        self._h = h
+
+    def arm(self):
+        check(self._lib.gs_timer_arm(self._h), 'gs_timer_arm')
+
+    def elapsed_us(self):
+        us = ctypes.c_float()
+        check(self._lib.gs_timer_elapsed_us(self._h, ctypes.byref(us)), 'gs_timer_elapsed_us')
+        return float(us.value)
+
+    def __del__(self):
+        try:
+            self._lib.gs_timer_destroy(self._h)
+        except Exception:
+            pass
+
+
 def hop_sizes(fanouts):
     out, p = [], 1
     for n in fanouts:

@@ -43,6 +43,20 @@ int gs_version(void);
 const char *gs_last_error(void);
 
 /*
+ * Exact timing of one launch, for benchmarks (no counterpart in the reference).
+ * A timer is a pair of HIP events.  gs_timer_arm(t) makes the calling thread's
+ * next launch of one of the path's main kernels (gs_sage2_forward,
+ * gs_sage_fused_fwd, gs_gather_mean_fwd / gs_gather_max_fwd) carry the pair in
+ * its own dispatch, so start and stop are the kernel's first and last cycle and
+ * nothing extra is enqueued; the timer disarms itself.  gs_timer_elapsed_us
+ * waits for that launch and returns its duration.  gs_timer_arm(NULL) disarms.
+ */
+int gs_timer_create(void **timer);
+int gs_timer_arm(void *timer);
+int gs_timer_elapsed_us(void *timer, float *microseconds);
+int gs_timer_destroy(void *timer);
+
+/*
  * Adjacency build: edge columns -> CSR.  Replaces Graph.get_neighbor_dict
  * (bipartite_graph.py:48-60: one np.where scan of the edge array per node) and,
  * with symmetric != 0, the edge doubling of train_movielens.py:130-132

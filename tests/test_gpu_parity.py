@@ -740,3 +740,21 @@ def test_projection_with_own_rows_gathered_in_the_kernel(cuda, m, fs, fn, h):
         assert torch.equal(got, want)
     with pytest.raises(ValueError):
         kernels.sage_project_gather(feat, ids_t[:-1].contiguous(), off, x_mean, ws, wn, b, 'relu')
+
+
+def test_launch_timer_brackets_exactly_one_kernel(cuda):
+    """gs_timer_*: the armed pair rides on the next gather-mean launch only."""
+    feat = torch.randn(200_000, 64, device=cuda)
+    ids = torch.randint(0, 200_000, (50_000 * 10,), device=cuda, dtype=torch.int32)
+    t = kernels.LaunchTimer()
+    t.arm()
+    a = kernels.gather_mean(feat, ids, 50_000, 10)
+    b = kernels.gather_mean(feat, ids, 50_000, 10)            # not timed: the timer disarmed itself
+    us = t.elapsed_us()
+    assert 1.0 < us < 5_000.0, us
+    assert torch.equal(a, b)
+    t2 = kernels.LaunchTimer()
+    t2.arm()
+    kernels.gather_rows(feat, ids[:1000].contiguous())        # not one of the timed kernels: stays armed
+    kernels.gather_mean(feat, ids, 50_000, 10)
+    assert t2.elapsed_us() > 1.0
