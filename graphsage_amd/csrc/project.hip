@@ -292,14 +292,11 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
         }                                                                                          \
     }
 
-    // Fragment registers in two named sets: while one set feeds the matrix pipe the other is being
-    // read from LDS, so neither the LDS latency nor the barrier sits between two runs of MFMAs.
-    //   per slice t:  read Y <- second half of slice t | MFMA X (first half) | store slice t+1 to the
-    //                 other stage, barrier | global loads (slice t+2) | read X <- first half of slice
-    //                 t+1 | MFMA Y (second half)
-    // The stage written in iteration t was last read (both halves) before the barrier of
-    // iteration t-1, which every wave has passed.
-    f32x4 aX0, aX1, aX2, aX3, bX0, bX1, bX2, bX3, aY0, aY1, aY2, aY3, bY0, bY1, bY2, bY3;
+    // One ds_read_b128 per 16x16 fragment feeds four MFMAs; the next slice's global loads are
+    // issued before the multiply and stored to the other LDS stage after it.  (A variant that
+    // also kept a second set of fragment registers to read LDS a phase ahead ran no faster alone
+    // and, at 226 instead of 167 registers, left less room for a gather kernel beside it.)
+    f32x4 aX0, aX1, aX2, aX3, bX0, bX1, bX2, bX3;
 #define GB_READ(S_, stage_, half_)                                                                  \
     {                                                                                              \
         const float *As_r = gb_smem + (stage_) * 2 * GB_TILE + ((half_) * 8 + wave_m * 4) * 256 + a_slot[half_] * 4; \
@@ -324,30 +321,24 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
         GB_MFMA_ROW(2, a##S_##2, S_, st) GB_MFMA_ROW(3, a##S_##3, S_, st)                          \
     }
 
-    static_assert(GB_K == 32, "the pipelined main loop walks two 16-wide halves per slice");
+    static_assert(GB_K == 32, "the main loop walks two 16-wide halves per slice");
     GB_LOAD_SLICE(0);
     GB_STORE_SLICE(0);
     __syncthreads();
-    GB_READ(X, 0, 0);
     const int n_slices = K / GB_K;
-    GB_LOAD_SLICE(min(1, n_slices - 1) * GB_K);
     for (int kt = 0; kt < n_slices; ++kt) {
         const int stage = kt & 1;
-        GB_READ(Y, stage, 1);
-        __builtin_amdgcn_sched_barrier(0);  // LDS reads are issued ahead of the multiply
+        // next slice in flight during the multiply; the last iteration re-reads its own slice (unused)
+        GB_LOAD_SLICE(min(kt + 1, n_slices - 1) * GB_K);
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the multiply (the scheduler would sink them)
+        GB_READ(X, stage, 0);
+        GB_MFMA(X);
+        GB_READ(X, stage, 1);
         GB_MFMA(X);
         __builtin_amdgcn_sched_barrier(0);
-        GB_STORE_SLICE(stage ^ 1);          // slice kt+1, loaded one whole iteration ago
+        GB_STORE_SLICE(stage ^ 1);          // that stage was last read before the previous barrier
         __syncthreads();
-        // slice kt+2 goes in flight now and is stored after the next iteration's first multiply; past
-        // the end the last slice is re-read (unused)
-        GB_LOAD_SLICE(min(kt + 2, n_slices - 1) * GB_K);
-        GB_READ(X, stage ^ 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        GB_MFMA(Y);
-        __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();                        // every wave is done with the stages before the epilogue reuses them
 #undef GB_READ
 #undef GB_MFMA_ROW
 #undef GB_MFMA
