@@ -86,6 +86,27 @@ class SageForwardEngine:
         # two hops: the whole forward pass as one kernel, one wavefront per walk
         self.walk_kernel = bool(use_fused and walk_kernel and self.n_hops == 2 and kernels.sage2_supported(
             f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'], *self.fanouts))
+        # Feature widths the one-kernel forward is not built for (MovieLens: 28 / 18 columns) are
+        # rounded up to the next multiple of 32 with zero columns in engine-owned copies of the
+        # tables, and the layer-0 weights get zero rows to match: the same function of the real
+        # features.  ``static_weights``: the padded weight copies are refreshed on every call unless
+        # the caller promises the weights do not change between calls.
+        self._padded = None
+        self.static_weights = False
+        if use_fused and walk_kernel and self.n_hops == 2 and not self.walk_kernel:
+            fp = {t: -(-f[t] // 32) * 32 for t in _TYPES}
+            if kernels.sage2_supported(fp['user'], fp['item'], model.dims[1]['user'], model.dims[2]['user'],
+                                       *self.fanouts):
+                tabs, wts = {}, {}
+                for t in _TYPES:
+                    src = self.tables[t][0]
+                    tabs[t] = torch.zeros((src.shape[0], fp[t]), dtype=torch.float32, device=device)
+                    tabs[t][:, :f[t]].copy_(src)
+                    hh = model.dims[1][t] // 2
+                    wts[(t, 'self')] = torch.zeros((fp[t], hh), dtype=torch.float32, device=device)
+                    wts[(t, 'neigh')] = torch.zeros((fp[other[t]], hh), dtype=torch.float32, device=device)
+                self._padded = {'tables': tabs, 'weights': wts, 'fresh': False}
+                self.walk_kernel = True
         self._walk_call = None
         self.emb_all = torch.empty((2 * b, model.dims[-1]['user']), dtype=torch.float32, device=device)
 
@@ -232,13 +253,26 @@ class SageForwardEngine:
 
     def forward_walks(self, seeds, walk_ids=None, rng_seed=0, replay=None):
         """sample + both layers + l2norm in one launch (two-hop models)."""
+        m = self.model
+        pad = self._padded
+        if pad is not None and not (self.static_weights and pad['fresh']):
+            with torch.no_grad():
+                for t in _TYPES:
+                    agg = m._aggs[0][t]
+                    pad['weights'][(t, 'self')][:agg.w_self.shape[0]].copy_(agg.w_self)
+                    pad['weights'][(t, 'neigh')][:agg.w_neigh.shape[0]].copy_(agg.w_neigh)
+            pad['fresh'] = True
         if self._walk_call is None:
-            m = self.model
             weights = {(l, t): (m._aggs[l][t].w_self, m._aggs[l][t].w_neigh, m._aggs[l][t].bias)
                        for l in (0, 1) for t in _TYPES}
-            self._walk_call = kernels.Sage2Call(self.indptr, self.indices, self.tables['user'][0],
-                                                self.tables['item'][0], self.fanouts, weights,
-                                                m.normalize == "l2", self.batch, emb=self.emb_all)
+            tables = {t: self.tables[t][0] for t in _TYPES}
+            if pad is not None:
+                tables = pad['tables']
+                for t in _TYPES:
+                    weights[(0, t)] = (pad['weights'][(t, 'self')], pad['weights'][(t, 'neigh')], m._aggs[0][t].bias)
+            self._walk_call = kernels.Sage2Call(self.indptr, self.indices, tables['user'], tables['item'],
+                                                self.fanouts, weights, m.normalize == "l2", self.batch,
+                                                emb=self.emb_all)
         if self.probes is not None:
             self._arm_probe()
         self._walk_call.run(seeds, self.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)

@@ -334,10 +334,10 @@ class Trainer:
     def _scores(self, seq, i):
         """(scores (b, 1), targets) of batch i: through the forward engine when the
         batch is a full one of a keyed sequence, else through the model."""
-        if (self.engine is not None and getattr(seq, '_indexed', False) and hasattr(seq, 'roots')
-                and not (self.model.dropout and self.model.training)):
+        if (self._graph_obj is not None and self._batch_size and getattr(seq, '_indexed', False)
+                and hasattr(seq, 'roots') and not (self.model.dropout and self.model.training)):
             seeds, walk_ids, key, y = seq.roots(i)
-            if seeds.numel() == 2 * self.engine.batch:
+            if seeds.numel() == 2 * int(self._batch_size):
                 if self._fwd_engine is None:
                     from .engine import SageForwardEngine
                     self._fwd_engine = SageForwardEngine(self._graph_obj, self.model, self._batch_size)

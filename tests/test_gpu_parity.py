@@ -647,7 +647,8 @@ def test_walk_kernel_replay_against_reference_batches(golden, cuda, case):
 
 @pytest.mark.parametrize('ns,sizes,fu,fi', [([25, 10], [32, 32], 64, 64), ([8, 4], [64, 64], 64, 64),
                                             ([10, 5], [32, 32], 64, 32), ([33, 7], [32, 32], 128, 128),
-                                            ([64, 3], [32, 64], 64, 64), ([3, 70], [32, 32], 32, 32)])
+                                            ([64, 3], [32, 64], 64, 64), ([3, 70], [32, 32], 32, 32),
+                                            ([10, 5], [32, 32], 24, 19), ([8, 4], [32, 32], 28, 18)])
 def test_walk_kernel_matches_layered_engine_and_oracle(cuda, ns, sizes, fu, fi):
     from graphsage_amd.engine import SageForwardEngine
     rng = np.random.default_rng(7)
@@ -686,6 +687,18 @@ def test_walk_kernel_matches_layered_engine_and_oracle(cuda, ns, sizes, fu, fi):
     eng_w.err_flag.zero_()
     eng_w.forward(bad, walk_ids, rng_seed=1)
     assert eng_w.err_flag.tolist()[1] == 1
+    if fu % 32:
+        # odd widths run on zero-padded copies of the tables and of the layer-0 weights; a weight
+        # change made behind torch's back (as the Adam kernel does) must still reach the copies
+        assert eng_w._padded is not None
+        agg = model._aggs[0]['user']
+        with torch.no_grad():
+            agg.w_self.mul_(0.5)
+        out2 = [x.clone() for x in eng_w.forward(seeds, walk_ids, rng_seed=4242)]
+        out3 = [x.clone() for x in eng_l.forward(seeds, walk_ids, rng_seed=4242)]
+        assert not torch.equal(out2[0], out_w[0])
+        for k in range(2):
+            close(out2[k], out3[k], scale=1.0)
 
 
 def test_engine_runs_the_max_aggregator_through_the_general_kernels(cuda):
