@@ -19,7 +19,8 @@ struct SampleParams {
     int size[GS_MAX_HOPS];      // slots per hop
     int off[GS_MAX_HOPS];       // offset of the hop inside one walk's tape
     int tape_len;               // words of tape per walk
-    int lds_per_buf;            // ints per LDS parent buffer (two per wave)
+    int lds_per_buf;            // ints per LDS parent buffer (two per wave); 0: parents are re-read
+                                // from the previous hop's output array instead (very wide hops)
     int32_t *out[GS_MAX_HOPS];
 };
 
@@ -55,8 +56,10 @@ void sample_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict
         const int total = P.size[h];
         const int32_t *par = (h & 1) ? buf0 : buf1;         // ids of hop h-1
         int32_t *cur = (h & 1) ? buf1 : buf0;               // ids of hop h
-        const bool keep = h + 1 < P.n_hops;
+        const bool use_lds = P.lds_per_buf > 0;
+        const bool keep = use_lds && h + 1 < P.n_hops;
         int32_t *dst = P.out[h] + (size_t)w * total;
+        const int32_t *prev = h ? P.out[h - 1] + (size_t)w * P.size[h - 1] : nullptr;
         // kChunks * 64 slots per pass: all row-bound loads of a pass are issued before the first
         // neighbor load, so a pass costs two dependent memory round trips however many slots it has
         for (int base = 0; base < total; base += kChunks * 64) {
@@ -66,7 +69,11 @@ void sample_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict
             for (int c = 0; c < kChunks; ++c) {
                 const int t = base + c * 64 + lane;
                 p[c] = -1;
-                if (t < total) p[c] = (h == 0) ? root : par[t / k];
+                if (t < total)
+                    p[c] = (h == 0) ? root
+                           : use_lds ? par[t / k]
+                                     // this wave's own stores of the previous hop, read back past the L1
+                                     : __hip_atomic_load(prev + t / k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int32_t pc = p[c] >= 0 ? p[c] : 0;    // node 0 stands in for dead slots
                 a[c] = indptr[pc];
                 b[c] = indptr[pc + 1];
@@ -94,10 +101,17 @@ void sample_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict
                 }
             }
         }
-        // make this hop's LDS writes visible to the other lanes of the wave
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // make this hop's writes visible to the other lanes of the wave (LDS, or memory when the
+        // parents are re-read from the output array)
+        if (use_lds) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
     }
 }
 
@@ -133,10 +147,11 @@ extern "C" int gs_sample(const int64_t *indptr, const int32_t *indices, int64_t 
     }
     P.tape_len = (int)off;
     P.lds_per_buf = n_hops >= 2 ? P.size[n_hops - 2] : 1;
-    const size_t lds_bytes = (size_t)kWavesPerBlock * 2 * P.lds_per_buf * sizeof(int32_t);
-    if (lds_bytes > 64 * 1024)
-        return gs::fail(GS_ELIMIT, "gs_sample: %d parent slots per walk need %zu B of LDS per block (limit 65536)",
-                        P.lds_per_buf, lds_bytes);
+    size_t lds_bytes = (size_t)kWavesPerBlock * 2 * P.lds_per_buf * sizeof(int32_t);
+    if (lds_bytes > 64 * 1024) {                    // hops too wide for LDS: parents come from the output arrays
+        P.lds_per_buf = 0;
+        lds_bytes = 0;
+    }
     const int64_t blocks = (n_seeds + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks > 0x7FFFFFFFLL) return gs::fail(GS_ELIMIT, "gs_sample: too many seeds for one launch");
 

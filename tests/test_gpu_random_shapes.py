@@ -1,0 +1,115 @@
+"""Seeded sweeps over odd shapes: every kernel entry point against numpy / the
+oracle on sizes that hit its tail paths (widths that are not multiples of the
+vector width, fan-outs above the wave width, single rows, many children) --
+needs a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from graphsage_amd import kernels
+from oracle import walker
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(rng, n_nodes, n_edges):
+    src = np.concatenate([np.arange(n_nodes), rng.integers(0, n_nodes, n_edges)]).astype(np.int32)
+    dst = rng.integers(0, n_nodes, src.size).astype(np.int32)
+    order = np.argsort(src, kind='stable')
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=n_nodes))]).astype(np.int64)
+    return src, dst, indptr, dst[order]
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_sampler_random_fanouts_against_the_oracle(cuda, seed):
+    rng = np.random.default_rng(seed)
+    n_nodes = int(rng.integers(5, 400))
+    src, dst, indptr, indices = _graph(rng, n_nodes, int(rng.integers(0, 3000)))
+    n_hops = int(rng.integers(1, 5))
+    fan = [int(rng.integers(1, [300, 40, 6, 3][h] + 1)) for h in range(n_hops)]
+    while np.prod(fan) > 20000:
+        fan[int(np.argmax(fan))] //= 2
+    roots = rng.integers(0, n_nodes, int(rng.integers(1, 70))).astype(np.int32)
+    key, base = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    a, b = torch.from_numpy(src).to(cuda), torch.from_numpy(dst).to(cuda)
+    d_indptr, d_indices = kernels.build_csr(a, b, n_nodes, sort_chunk=int(rng.choice([0, 17, 1000])))
+    np.testing.assert_array_equal(d_indptr.cpu().numpy(), indptr)
+    np.testing.assert_array_equal(d_indices.cpu().numpy(), indices)
+    hops, err = kernels.sample(d_indptr, d_indices, torch.from_numpy(roots).to(cuda), fan, rng_seed=key, walk_id_base=base)
+    assert err.tolist() == [0, 0]
+    want = walker.walk_vectorised(indptr, indices, roots, fan, rng_seed=key, first_walk=base)
+    for got, w in zip(hops, want):
+        np.testing.assert_array_equal(got.cpu().numpy(), w)
+    # the same draws from a tape
+    sizes = walker.hop_sizes(fan)
+    tape = rng.integers(0, 2 ** 32, len(roots) * sum(sizes), dtype=np.uint64).astype(np.uint32)
+    hops, _ = kernels.sample(d_indptr, d_indices, torch.from_numpy(roots).to(cuda), fan,
+                             replay=torch.from_numpy(tape.view(np.int32)).to(cuda))
+    want = walker.walk_vectorised(indptr, indices, roots, fan, tape=tape)
+    for got, w in zip(hops, want):
+        np.testing.assert_array_equal(got.cpu().numpy(), w)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_gather_and_reduce_random_shapes(cuda, seed):
+    rng = np.random.default_rng(100 + seed)
+    f = int(rng.choice([1, 2, 3, 5, 7, 12, 18, 24, 28, 33, 64, 100, 130, 256, 514]))
+    n_rows = int(rng.integers(1, 3000))
+    n_child = int(rng.choice([1, 2, 3, 9, 25, 64, 130, 700]))
+    n_parents = int(rng.integers(1, 200 if n_child < 100 else 20))
+    off = int(rng.integers(0, 1000))
+    feat = rng.standard_normal((n_rows, f)).astype(np.float32)
+    ids = rng.integers(0, n_rows, (n_parents, n_child)).astype(np.int32)
+    t, d_ids = torch.from_numpy(feat).to(cuda), torch.from_numpy(ids + off).to(cuda).reshape(-1)
+    rows = kernels.gather_rows(t, d_ids, off)
+    np.testing.assert_array_equal(rows.cpu().numpy(), feat[ids.reshape(-1)])
+    mean = kernels.gather_mean(t, d_ids, n_parents, n_child, off).cpu().numpy()
+    want = feat[ids].astype(np.float64).mean(axis=1)
+    assert np.abs(mean - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    mx = kernels.gather_max(t, d_ids, n_parents, n_child, off).cpu().numpy()
+    np.testing.assert_array_equal(mx, feat[ids].max(axis=1))
+    # dense groups and their gradients
+    m = (n_rows // n_child)
+    if m:
+        dense = t[:m * n_child].contiguous()
+        got = kernels.gather_mean(dense, None, m, n_child).cpu().numpy()
+        want = feat[:m * n_child].reshape(m, n_child, f).astype(np.float64).mean(axis=1)
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+        g = torch.from_numpy(rng.standard_normal((m, f)).astype(np.float32)).to(cuda)
+        gx = torch.empty_like(dense)
+        kernels.gather_mean_bwd(g, None, n_child, gx)
+        np.testing.assert_allclose(gx.cpu().numpy().reshape(m, n_child, f),
+                                   np.repeat((g.cpu().numpy() / np.float32(n_child))[:, None, :], n_child, axis=1),
+                                   rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_projection_random_shapes_forward_and_backward(cuda, seed):
+    rng = np.random.default_rng(200 + seed)
+    m = int(rng.choice([1, 3, 63, 64, 65, 127, 500, 513, 1030]))
+    fs, fn = int(rng.choice([1, 5, 19, 24, 32, 64, 96, 128, 160])), int(rng.choice([1, 7, 18, 28, 32, 64, 128]))
+    h = 2 * int(rng.choice([1, 3, 8, 16, 20, 32, 64, 128]))
+    act = str(rng.choice(['relu', 'linear']))
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(cuda)
+    xs, xm = rng.standard_normal((m, fs)), rng.standard_normal((m, fn))
+    ws, wn, b = 0.3 * rng.standard_normal((fs, h // 2)), 0.3 * rng.standard_normal((fn, h // 2)), rng.standard_normal(h)
+    out = kernels.sage_project(f32(xs), f32(xm), f32(ws), f32(wn), f32(b), act)
+    z = np.concatenate([xs.astype(np.float32).astype(np.float64) @ ws.astype(np.float32).astype(np.float64),
+                        xm.astype(np.float32).astype(np.float64) @ wn.astype(np.float32).astype(np.float64)], axis=1)
+    z = z + b.astype(np.float32).astype(np.float64)
+    want = np.maximum(z, 0) if act == 'relu' else z
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(out.cpu().numpy() - want).max() <= 2e-5 * scale
+    # backward against the same formulas
+    g = rng.standard_normal((m, h)).astype(np.float32)
+    res = dict(zip(('g_w_self', 'g_w_neigh', 'g_bias', 'g_x_self', 'g_x_mean'),
+                   kernels.sage_project_bwd(f32(xs), f32(xm), f32(ws), f32(wn), act, out, f32(g))))
+    gm = g.astype(np.float64) * ((want > 0) if act == 'relu' else 1.0)
+    x32s, x32m = xs.astype(np.float32).astype(np.float64), xm.astype(np.float32).astype(np.float64)
+    wants = {'g_w_self': x32s.T @ gm[:, :h // 2], 'g_w_neigh': x32m.T @ gm[:, h // 2:], 'g_bias': gm.sum(0),
+             'g_x_self': gm[:, :h // 2] @ ws.astype(np.float32).astype(np.float64).T,
+             'g_x_mean': gm[:, h // 2:] @ wn.astype(np.float32).astype(np.float64).T}
+    for name, w in wants.items():
+        got = res[name].cpu().numpy()
+        assert got.shape == w.shape, name
+        assert np.abs(got - w).max() <= 3e-5 * max(1.0, np.abs(w).max()), name
