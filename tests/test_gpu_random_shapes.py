@@ -113,3 +113,58 @@ def test_projection_random_shapes_forward_and_backward(cuda, seed):
         got = res[name].cpu().numpy()
         assert got.shape == w.shape, name
         assert np.abs(got - w).max() <= 3e-5 * max(1.0, np.abs(w).max()), name
+
+
+@pytest.mark.parametrize('seed', range(14))
+def test_forward_engine_random_models_against_the_oracle(cuda, seed):
+    """Whatever route the engine picks for the shape (one kernel, padded one kernel,
+    fused layers, general kernels; mean or max), embeddings equal the float64 oracle
+    applied to the ids the kernels sampled."""
+    import graphsage_amd as ga
+    from graphsage_amd.engine import SageForwardEngine
+    from oracle import generator as ogen
+    from oracle import model as omodel
+    rng = np.random.default_rng(300 + seed)
+    n_hops = int(rng.choice([1, 2, 2, 2, 3]))
+    fan = [int(rng.integers(1, [12, 6, 3][h] + 1)) for h in range(n_hops)]
+    fu, fi = int(rng.choice([8, 19, 24, 32, 64])), int(rng.choice([5, 18, 32, 64]))
+    sizes = [int(rng.choice([4, 16, 32, 64])) for _ in range(n_hops)]
+    agg = 'max' if seed % 5 == 4 else 'mean'
+    nu, ni, b = int(rng.integers(20, 300)), int(rng.integers(5, 60)), int(rng.integers(1, 40))
+    u = np.concatenate([rng.integers(0, nu, 1500), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 1500), np.arange(nu) % ni]) + nu
+    it[-nu:][np.arange(nu) % ni >= ni] = nu                       # (no-op guard: ids stay in range)
+    for extra in range(ni):                                        # every item gets a neighbor
+        u, it = np.append(u, extra % nu), np.append(it, nu + extra)
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, fu)).astype(np.float32),
+             'item': rng.standard_normal((ni, fi)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))}, np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, b, fan, head_node_types=['user', 'item'], seed=seed)
+    model = ga.GraphSAGE(sizes, gen, agg_option=agg, seed=seed + 1).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.2, 0.2)
+    pick = rng.integers(0, e.shape[1], b)
+    links = [(int(e[0, i]), int(e[1, i])) for i in pick]
+    seeds = torch.tensor([l[0] for l in links] + [l[1] for l in links], dtype=torch.int32, device=cuda)
+    walk_ids = torch.from_numpy(rng.integers(0, 2 ** 40, 2 * b)).to(cuda)
+    eng = SageForwardEngine(g, model, b)
+    out = [x.clone() for x in eng.forward(seeds, walk_ids, rng_seed=seed * 7 + 1)]
+    assert eng.err_flag.tolist() == [0, 0]
+    # the draws are a function of (key, walk id, hop, slot): the oracle reproduces them walk by walk
+    hops = [np.empty((2 * b, s), dtype=np.int64) for s in walker.hop_sizes(fan)]
+    wid = walk_ids.cpu().numpy()
+    for w in range(2 * b):
+        one = walker.walk_vectorised(g.indptr, g.indices, seeds[w:w + 1].cpu().numpy(), fan, rng_seed=seed * 7 + 1,
+                                     first_walk=int(wid[w]))
+        for h in range(n_hops):
+            hops[h][w] = one[h][0]
+    xin = ogen.sample_features_fast({k: v.astype(np.float64) for k, v in feats.items()}, nu, links, hops)
+    plan = omodel.LayerPlan(sizes, fan, g.node_feature_sizes)
+    weights = {(l, t): {'w_self': a.w_self.detach().cpu().double(), 'w_neigh': a.w_neigh.detach().cpu().double(),
+                        'bias': a.bias.detach().cpu().double()}
+               for l, per in enumerate(model._aggs) for t, a in per.items()}
+    want = omodel.forward(plan, weights, [torch.from_numpy(x) for x in xin], agg=agg)
+    for k in range(2):
+        assert (out[k].cpu().double() - want[k]).abs().max().item() <= 1e-5, (n_hops, fan, fu, fi, sizes, agg)

@@ -97,7 +97,9 @@ def test_short_run_learns(cuda):
     assert auc > 0.8, auc
 
 
-@pytest.mark.parametrize('ns,sizes,f', [([8, 4], [32, 32], 64), ([5, 3, 2], [32, 64, 32], 32)])
+@pytest.mark.parametrize('ns,sizes,f', [([8, 4], [32, 32], 64), ([5, 3, 2], [32, 64, 32], 32), ([25, 10], [32, 32], 64),
+                                        ([3, 2], [32, 32], 128), ([10, 5], [64, 32], 32), ([7], [32], 64),
+                                        ([2, 2, 2, 2], [32, 32, 32, 32], 32), ([12, 1], [32, 64], 64)])
 def test_plan_engine_step_equals_autograd_step(cuda, ns, sizes, f):
     """The static training plan (fused forward with saved activations + kernel
     backward) produces the same loss, gradients and updated weights as the
