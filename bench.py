@@ -34,6 +34,9 @@ WORKLOADS = {
     'cfg5': dict(nu=1_000_000, ni=100_000, e=50_000_000, fu=256, fi=256, fan=[25, 10, 5], layers=[256, 256, 256],
                  alpha_item=1.1, alpha_user=None,
                  desc="cfg2 graph, 3-hop [25,10,5], 256-d features, 256 hidden"),
+    'cfg2w64': dict(nu=1_000_000, ni=100_000, e=50_000_000, fu=64, fi=64, fan=[25, 10], layers=[64, 64],
+                    alpha_item=1.1, alpha_user=None,
+                    desc="cfg2 with 64 hidden units per layer instead of the reference's 32"),
     'cfg2h3': dict(nu=1_000_000, ni=100_000, e=50_000_000, fu=64, fi=64, fan=[25, 10, 5], layers=[32, 32, 32],
                    alpha_item=1.1, alpha_user=None,
                    desc="cfg2 graph and widths, 3-hop [25,10,5] (layered path: sampler + one fused kernel per layer and type)"),

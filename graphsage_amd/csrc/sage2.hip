@@ -32,10 +32,15 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kWaves = 16;               // most waves per block: one block per CU, 4 waves per SIMD
+// Waves per block (one block per CU).  With 32-wide activations everything a wave keeps in LDS lets
+// sixteen waves fit: four per SIMD, 128 registers each, one head's children in flight per lane
+// group.  64-wide activations double the weights and the activation rows, at most eight waves
+// fit, so those instantiations are built for eight waves (two per SIMD, 256 registers each) and
+// keep two heads' children in flight per lane group instead: the same bytes in flight per CU.
+constexpr int max_waves(int hh1) { return hh1 >= 32 ? 8 : 16; }
+constexpr int heads_in_flight(int hh1) { return hh1 >= 32 ? 2 : 1; }
 constexpr int kUnroll = 10;              // row loads in flight per lane in the mean phase
 constexpr int kChunks = 4;               // 64-slot chunks sampled per pass
-constexpr int kHeads = 1;                // heads per lane group whose row loads are issued together
 constexpr size_t kLdsMax = 160 * 1024;
 
 struct Sage2Args {
@@ -268,6 +273,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             const int g = lane / FTV, c = lane % FTV;
             const unsigned col = (unsigned)c * 16u;
             const float denom = (float)n1;
+            constexpr int kHeads = heads_in_flight(HH1);
             for (int pp0 = g; pp0 < 16; pp0 += kHeads * GN_T) {
                 float4 acc[kHeads];
 #pragma unroll
@@ -448,7 +454,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
 }
 
 template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE>
-__global__ __launch_bounds__(kWaves * 64)
+__global__ __launch_bounds__(max_waves(HH1) * 64)
 void sage2_kernel(const Sage2Args a) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     constexpr int H1 = S::H1, H2 = S::H2, LDA = S::LDA, LDH = S::LDH;
@@ -520,7 +526,7 @@ void sage2_kernel(const Sage2Args a) {
 template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE>
 int launch_one(const Sage2Args &a, hipStream_t stream) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
-    int waves = kWaves;                                  // as many waves per CU as the LDS budget admits
+    int waves = max_waves(HH1);                          // as many waves per CU as the LDS budget admits
     while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves) > kLdsMax) waves -= 2;
     const size_t lds = S::lds_bytes(a.n0, a.n1, waves);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
