@@ -124,18 +124,34 @@ struct RowTable {
 };
 
 // D[16 x 16*NT] += A[16 x K] . W[K x 16*NT]; A in LDS (row stride lda), W in fragment order.
+// Operands are fetched in batches of 64 k (four 16-byte A reads, 16*NT weight words) ahead of
+// the MFMAs that use them, so the LDS latency is paid once per batch, not once per MFMA pair.
 template <int K, int NT>
 __device__ __forceinline__ void mma_tile(const float *A, int lda, const float *Wl, int wl, int r, int q,
                                          f32x4 (&acc)[NT]) {
+    constexpr int KB = K < 64 ? K : 64;                  // k per batch
 #pragma unroll
-    for (int k4 = 0; k4 < K / 16; ++k4) {
-        const float4 av = *reinterpret_cast<const float4 *>(A + r * lda + q * (K / 4) + 4 * k4);
-        const float ae[4] = {av.x, av.y, av.z, av.w};
+    for (int kb = 0; kb < K; kb += KB) {
+        float4 av[KB / 16];
+        float wv[KB / 4][NT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int k4 = 0; k4 < KB / 16; ++k4)
+            av[k4] = *reinterpret_cast<const float4 *>(A + r * lda + q * (K / 4) + kb / 4 + 4 * k4);
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], Wl[((4 * k4 + e) * NT + ct) * 64 + wl], acc[ct], 0, 0, 0);
+        for (int ks = 0; ks < KB / 4; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) wv[ks][ct] = Wl[((kb / 4 + ks) * NT + ct) * 64 + wl];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k4 = 0; k4 < KB / 16; ++k4) {
+            const float ae[4] = {av[k4].x, av[k4].y, av[k4].z, av[k4].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], wv[4 * k4 + e][ct], acc[ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
