@@ -146,6 +146,21 @@ class LinkSequence:
         seeds, walk_ids, key = self._sample_features.roots(head_ids, batch_indices, self.epoch)
         return seeds, walk_ids, key, (None if self.targets is None else self.targets[batch_indices])
 
+    def epoch_on_device(self):
+        """Every FULL batch of the current epoch staged on the GPU with one copy per
+        array: dict(roots int32[n, 2b] -- sources then destinations per row --,
+        walk_ids int64[n, 2b], targets float32[n, b] or None, key, n_batches).
+        A loop that feeds the kernels from these rows pays no per-batch host work."""
+        if not self._indexed:
+            raise TypeError("this sequence's sampling function does not key draws by link")
+        if getattr(self, '_staged_epoch', None) == self.epoch:
+            return self._staged
+        n_full = self.data_size // self.batch_size
+        idx = np.asarray(self.indices[:n_full * self.batch_size], dtype=np.int64)
+        self._staged = self._sample_features.stage(self.ids, idx, n_full, self.batch_size, self.targets, self.epoch)
+        self._staged_epoch = self.epoch
+        return self._staged
+
     def __iter__(self):
         for b in range(len(self)):
             yield self[b]
@@ -229,6 +244,32 @@ class _IndexedSampler:
     def roots(self, head_links, link_index, epoch):
         roots, walk_ids, _ = self._gen._roots(head_links, link_index)
         return roots, walk_ids, _mix64(self._gen._base_seed(), epoch)
+
+    def stage(self, ids, idx, n_full, b, targets, epoch):
+        import torch
+        from ._lib import require_gpu
+        dev = require_gpu()
+        gen = self._gen
+        if getattr(self, '_links_src', None) is not ids:            # the id list as an array, made once
+            self._links_np = np.asarray([(l[0], l[1]) for l in ids], dtype=np.int64).reshape(-1, 2)
+            self._links_src = ids
+        links = self._links_np[idx]
+        n = gen.graph.num_users + gen.graph.num_items
+        if links.size and (links.min() < 0 or links.max() >= n):
+            raise KeyError(int(links[(links < 0) | (links >= n)][0]))
+        present = getattr(gen.graph, '_present', None)
+        if links.size and present is not None and not present[links].all():
+            raise KeyError(int(links[~present[links]][0]))
+        per = links.reshape(n_full, b, 2)
+        roots = np.concatenate([per[:, :, 0], per[:, :, 1]], axis=1).astype(np.int32)
+        li = idx.reshape(n_full, b)
+        walk = np.concatenate([2 * li, 2 * li + 1], axis=1)
+        out = {'roots': torch.from_numpy(np.ascontiguousarray(roots)).to(dev),
+               'walk_ids': torch.from_numpy(np.ascontiguousarray(walk)).to(dev),
+               'targets': None, 'key': _mix64(gen._base_seed(), epoch), 'n_batches': n_full}
+        if targets is not None:
+            out['targets'] = torch.from_numpy(np.asarray(targets, dtype=np.float32)[idx].reshape(n_full, b)).to(dev)
+        return out
 
 
 class GraphSAGEGenerator(BatchedLinkGenerator):

@@ -16,6 +16,7 @@ kernels too; the torch formulations below them serve host tensors (tests under
 gloo) and the autograd path.
 """
 import math
+import time
 
 import numpy as np
 import torch
@@ -288,38 +289,56 @@ class Trainer:
         history = {}
         dev = self.bucket.flat.device
         for epoch in range(epochs):
+            t_epoch = time.perf_counter()
             mets = self._metrics()
-            loss_sum, seen = torch.zeros((), dtype=torch.float64, device=dev), 0
+            ys, preds, losses = [], [], []                     # metrics are sums: taken once, after the pass
+            staged = None
+            if (self.engine is not None and getattr(train_seq, '_indexed', False) and train_seq.targets is not None
+                    and train_seq.batch_size == self.engine.batch):
+                staged = train_seq.epoch_on_device()           # every full batch of the epoch, one copy
             for i in range(self._common_batches(train_seq)):
-                planned = self.engine is not None and hasattr(train_seq, 'roots') and train_seq._indexed
-                if planned:
-                    seeds, walk_ids, key, y = train_seq.roots(i)
-                    planned = seeds.numel() == 2 * self.engine.batch
-                if planned:
-                    y_dev = torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)
+                if staged is not None and i < staged['n_batches']:
+                    y_dev = staged['targets'][i]
                     # replayed HIP graph; loss and pred are its static outputs, consumed (in stream
                     # order) by the metric updates below before the next replay overwrites them
-                    loss, pred = self.step_graph(seeds, y_dev, walk_ids, key)
+                    loss, pred = self.step_graph(staged['roots'][i], y_dev, staged['walk_ids'][i], staged['key'])
                 else:
                     batch, y = train_seq[i]
                     y_dev = torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)
                     loss, pred = self.step(batch, y_dev)
-                n = y_dev.numel()
-                loss_sum += loss.detach().double().reshape(()) * n
-                seen += n
-                for m in mets:
-                    m.update_state(y_dev, pred)
-            logs = {'loss': float(loss_sum) / max(seen, 1)}
-            logs.update({m.name: m.result() for m in mets})
+                ys.append(y_dev.reshape(-1))
+                preds.append(pred.detach().reshape(-1).clone())
+                losses.append(loss.detach().reshape(1).clone())
+            logs = self._epoch_logs(mets, ys, preds, losses)
             self._raise_sampling_errors()
             if validation_data is not None:
                 logs.update({'val_' + k: v for k, v in self.evaluate(validation_data).items()})
             for k, v in logs.items():
                 history.setdefault(k, []).append(v)
             if verbose:
-                print("Epoch %d/%d - %s" % (epoch + 1, epochs, " - ".join("%s: %.4f" % kv for kv in logs.items())))
+                print("Epoch %d/%d - %.1fs - %s" % (epoch + 1, epochs, time.perf_counter() - t_epoch,
+                                                    " - ".join("%s: %.4f" % kv for kv in logs.items())))
             train_seq.on_epoch_end()
         return history
+
+    @staticmethod
+    def _epoch_logs(mets, ys, preds, losses, chunk=1 << 16):
+        """{'loss', metric names...} of one pass from its per-batch targets, scores
+        and (for training, where the weights move between batches) batch losses;
+        without ``losses`` the loss is the mean squared error of the scores."""
+        if not ys:
+            return dict({'loss': 0.0}, **{m.name: m.result() for m in mets})
+        sizes = [t.numel() for t in ys]
+        y_all, p_all = torch.cat(ys), torch.cat(preds)
+        if losses is None:
+            loss = float(((p_all.double() - y_all.double()) ** 2).mean())
+        else:
+            w = torch.tensor(sizes, dtype=torch.float64, device=y_all.device)
+            loss = float((torch.cat(losses).double() * w).sum() / w.sum())
+        for lo in range(0, y_all.numel(), chunk):
+            for m in mets:
+                m.update_state(y_all[lo:lo + chunk], p_all[lo:lo + chunk])
+        return dict({'loss': loss}, **{m.name: m.result() for m in mets})
 
     def _raise_sampling_errors(self):
         """The engines only flag a node without neighbors or an unknown root (the
@@ -335,13 +354,14 @@ class Trainer:
         """(scores (b, 1), targets) of batch i: through the forward engine when the
         batch is a full one of a keyed sequence, else through the model."""
         if (self._graph_obj is not None and self._batch_size and getattr(seq, '_indexed', False)
-                and hasattr(seq, 'roots') and not (self.model.dropout and self.model.training)):
-            seeds, walk_ids, key, y = seq.roots(i)
-            if seeds.numel() == 2 * int(self._batch_size):
+                and seq.batch_size == int(self._batch_size) and not (self.model.dropout and self.model.training)):
+            staged = seq.epoch_on_device()
+            if i < staged['n_batches']:
                 if self._fwd_engine is None:
                     from .engine import SageForwardEngine
                     self._fwd_engine = SageForwardEngine(self._graph_obj, self.model, self._batch_size)
-                emb = self._fwd_engine.forward(seeds, walk_ids, rng_seed=key)
+                emb = self._fwd_engine.forward(staged['roots'][i], staged['walk_ids'][i], rng_seed=staged['key'])
+                y = None if staged['targets'] is None else staged['targets'][i]
                 return self.head(emb), y
         batch, y = seq[i]
         return self.head(self.model(batch)), y
@@ -350,18 +370,13 @@ class Trainer:
     def evaluate(self, seq):
         """Loss and metrics of the current weights over a sequence (no update)."""
         dev = self.bucket.flat.device
-        mets = self._metrics()
-        loss_sum, seen = torch.zeros((), dtype=torch.float64, device=dev), 0
+        ys, preds = [], []
         for i in range(len(seq)):
             pred, y = self._scores(seq, i)
-            y_dev = torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)
-            loss = ((pred - y_dev.reshape(pred.shape)) ** 2).mean()
-            loss_sum += loss.double() * y_dev.numel()
-            seen += y_dev.numel()
-            for m in mets:
-                m.update_state(y_dev, pred)
-        out = {'loss': float(loss_sum) / max(seen, 1)}
-        out.update({m.name: m.result() for m in mets})
+            ys.append((y if isinstance(y, torch.Tensor)
+                       else torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)).reshape(-1))
+            preds.append(pred.reshape(-1))
+        out = self._epoch_logs(self._metrics(), ys, preds, None)
         self._raise_sampling_errors()
         return out
 

@@ -285,3 +285,21 @@ def test_fit_surfaces_a_node_without_neighbors_like_the_reference(cuda):
     assert str(ei.value).startswith("Samples must exist. Self-node also can be a sample")
     with pytest.raises(KeyError):                      # the same error is a KeyError too, as the dict lookup gives
         tr.evaluate(seq)
+
+
+def test_staged_epoch_rows_equal_the_per_batch_roots(cuda):
+    graph, links, y = _toy(seed=5)
+    gen = ga.GraphSAGEGenerator(graph, 16, [3, 2], head_node_types=['user', 'item'], seed=9)
+    seq = gen.flow(links, targets=y, shuffle=True, seed=2)
+    for _ in range(2):                                           # a second epoch re-stages in the new order
+        st = seq.epoch_on_device()
+        assert st['n_batches'] == len(links) // 16 and st is seq.epoch_on_device()
+        for i in range(st['n_batches']):
+            seeds, walk_ids, key, t = seq.roots(i)
+            assert torch.equal(st['roots'][i], seeds) and torch.equal(st['walk_ids'][i], walk_ids)
+            assert key == st['key']
+            np.testing.assert_array_equal(st['targets'][i].cpu().numpy(), np.asarray(t, dtype=np.float32))
+        seq.on_epoch_end()
+    bad = gen.flow(links[:31] + [(links[0][0], 10 ** 6)], targets=np.zeros(32), shuffle=False)
+    with pytest.raises(KeyError):                                # unknown node in a later link, as roots() raises
+        bad.epoch_on_device()
