@@ -190,7 +190,7 @@ def main():
     del u, it
     gen = ga.GraphSAGEGenerator(graph, b, cfg['fan'], head_node_types=['user', 'item'], seed=0x9E3779B97F4A7C15)
     model = ga.GraphSAGE(cfg['layers'], gen, seed=7).build()
-    engine = SageForwardEngine(graph, model, b)
+    engine = SageForwardEngine(graph, model, b, use_fused=not os.environ.get('BENCH_UNFUSED'))
     engine.static_weights = True         # inference: padded weight copies (odd feature widths) are made once
 
     # per-step inputs, resident in HBM: roots (sources then destinations) and the walk ids

@@ -26,38 +26,18 @@
 //              contiguous stores per row and half.
 // After the one-time weight staging, waves never synchronise with each other:
 // all LDS hand-offs are wave-local.
-#include "gs_common.h"
+#include "fused_args.h"
 
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kWaves = 4;
-constexpr int kMaxSegs = 2 * GS_MAX_HOPS;
+using gs::FusedArgs;
+using gs::Seg;
+using gs::kMaxSegs;
 constexpr int kUnroll = 10;
 constexpr size_t kLdsLimit = 64 * 1024;
-
-struct Seg {
-    const int32_t *head_ids;   // node ids of the heads, or NULL: heads are rows self_row0 + p of feat_self
-    const int32_t *child_ids;  // node ids of the children [n_heads * n_child], or NULL: rows child_row0 + p*n_child + j
-    long long n_heads;
-    long long self_row0;
-    long long child_row0;
-    long long tile0;           // index of the segment's first tile
-    long long out_row0;        // first output row of the segment
-    int n_child;
-};
-
-struct FusedArgs {
-    const float *feat_self;  long long n_rows_self;  long long off_self;
-    const float *feat_neigh; long long n_rows_neigh; long long off_neigh;
-    const float *W_self, *W_neigh, *bias;
-    float *out, *save_self, *save_mean;
-    Seg seg[kMaxSegs];
-    int n_segs;
-    long long n_tiles;
-    int act, normalize, max_child;
-};
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -299,12 +279,17 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int gs_sage_fused_supported(int Fs, int Fn, int H, int max_child) {
+// shapes of the one-wave-per-16-heads kernel of this file
+static bool narrow_supported(int Fs, int Fn, int H, int max_child) {
     const int hh = H / 2;
     const bool f_ok = (Fs == 32 || Fs == 64 || Fs == 128) && (Fn == 32 || Fn == 64 || Fn == 128);
     const bool h_ok = (H % 2 == 0) && (hh == 16 || hh == 32);
     if (!f_ok || !h_ok || max_child < 1) return 0;
     return fused_lds_bytes(Fs, Fn, hh, max_child) <= kLdsLimit;
+}
+
+extern "C" int gs_sage_fused_supported(int Fs, int Fn, int H, int max_child) {
+    return narrow_supported(Fs, Fn, H, max_child) || gs::sage_wide_supported(Fs, Fn, H, max_child);
 }
 
 extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
@@ -352,6 +337,7 @@ extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, in
     a.out = out; a.save_self = save_self; a.save_mean = save_mean;
     a.n_segs = n_segs; a.n_tiles = tiles; a.act = act; a.normalize = normalize; a.max_child = max_child;
     hipStream_t s = (hipStream_t)stream;
+    if (!narrow_supported(Fs, Fn, H, max_child)) return gs::sage_wide_fwd(a, Fs, Fn, H, s);   // wide layers: wide.hip
     const int hh = H / 2;
 #define GS_CASE(fs, fn, h2) if (Fs == fs && Fn == fn && hh == h2) return launch<fs, fn, h2>(a, s);
     GS_CASE(64, 64, 16) GS_CASE(64, 64, 32)

@@ -83,6 +83,12 @@ class SageForwardEngine:
         self.use_fused = use_fused
         self.fused_layers = [self._fused_ok(layer) and use_fused for layer in range(self.n_hops)]
         self._fused_calls = {}
+        # Wide layers (half output width a multiple of 128) go through the kernel that overlaps the
+        # gathers with the projection.  It pays where the gathers are large, i.e. in layer 0; the later
+        # layers have few rows, where a launch of one 128-row tile per compute unit is mostly latency,
+        # and run on the general kernels.
+        self.wide_first_layer_only = (use_fused and self.n_hops > 1 and
+                                      all(model.dims[1][t] // 2 >= 128 for t in _TYPES))
         # two hops: the whole forward pass as one kernel, one wavefront per walk
         self.walk_kernel = bool(use_fused and walk_kernel and self.n_hops == 2 and kernels.sage2_supported(
             f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'], *self.fanouts))
@@ -172,6 +178,12 @@ class SageForwardEngine:
                                                 agg.w_self, agg.w_neigh, agg.bias, agg.activation,
                                                 out=self.h[0][t][r0:r0 + n])
         main.wait_stream(self._side)
+        return self._aggregate_tail()
+
+    def _aggregate_tail(self):
+        """Layers 1..L-1 and the normalisation with the general kernels, on layer 0's output."""
+        m = self.model
+        other = self.other
         for layer in range(1, self.n_hops):
             for t in _TYPES:
                 for (s, h, side, r0, n) in self.segments[t]:
@@ -247,6 +259,9 @@ class SageForwardEngine:
         """Same result as ``aggregate`` with one kernel per (layer, node type)."""
         if not all(self.fused_layers):
             return self.aggregate(seeds)
+        if self.wide_first_layer_only:
+            self._run_fused_layer(0, seeds)
+            return self._aggregate_tail()
         for layer in range(self.n_hops):
             self._run_fused_layer(layer, seeds)
         return self.emb['user'], self.emb['item']

@@ -492,7 +492,8 @@ def test_aggregator_layer_call_convention(cuda):
 
 # ------------------------------------------------- fused layer and engine ----
 
-@pytest.mark.parametrize('fs,fn,h', [(64, 64, 32), (32, 32, 32), (64, 64, 64), (128, 64, 32), (32, 128, 64)])
+@pytest.mark.parametrize('fs,fn,h', [(64, 64, 32), (32, 32, 32), (64, 64, 64), (128, 64, 32), (32, 128, 64),
+                                     (256, 256, 256), (64, 128, 256), (128, 96, 512)])   # the last three: wide kernel
 @pytest.mark.parametrize('act,normalize', [('relu', False), ('linear', True)])
 def test_fused_layer_matches_oracle(cuda, fs, fn, h, act, normalize):
     rng = np.random.default_rng(fs + fn + h)
@@ -549,11 +550,62 @@ def test_fused_layer_matches_oracle(cuda, fs, fn, h, act, normalize):
     with pytest.raises(Exception):                            # dense rows beyond the table
         kernels.sage_fused(d(t_self), 0, d(t_neigh), 0, [{'n_heads': 100, 'n_child': 5, 'child_row0': 0}],
                            f32(ws), f32(wn), None, act)
-    assert not kernels.fused_supported(24, 19, 32, 8) and not kernels.fused_supported(256, 256, 256, 5)
+    assert not kernels.fused_supported(24, 19, 32, 8) and not kernels.fused_supported(256, 256, 256, 40)
+    assert not kernels.fused_supported(48, 64, 256, 5) and kernels.fused_supported(256, 256, 256, 5)
+
+
+@pytest.mark.parametrize('fs,fn,h,n_child', [(64, 96, 256, 5), (256, 256, 256, 12), (64, 64, 256, 32)])
+def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_child):
+    """More 128-head tiles than blocks: every block walks several tiles (ids staged one
+    tile ahead, operand stages alternating across tile borders).  Checked against gather +
+    gather-mean + projection, and a sample of rows against the float64 oracle."""
+    rng = np.random.default_rng(fs + n_child)
+    gen = torch.Generator().manual_seed(h + n_child)
+    n_self, n_neigh, off_s, off_n = 5000, 3000, 7, 6000
+    t_self = torch.from_numpy(rng.standard_normal((n_self, fs)).astype(np.float32)).to(cuda)
+    t_neigh = torch.from_numpy(rng.standard_normal((n_neigh, fn)).astype(np.float32)).to(cuda)
+    ws = omodel.glorot_uniform(fs, h // 2, gen, torch.float64)
+    wn = omodel.glorot_uniform(fn, h // 2, gen, torch.float64)
+    bias = torch.randn(h, generator=gen, dtype=torch.float64) * 0.1
+    f32 = lambda t: t.float().to(cuda).contiguous()
+    segs, want = [], []
+    for n_heads, nc in [(300 * 128 + 5, n_child), (77, 3), (2 * 128, 1)]:
+        heads = torch.from_numpy(rng.integers(0, n_self, n_heads).astype(np.int32) + off_s).to(cuda)
+        kids = torch.from_numpy(rng.integers(0, n_neigh, n_heads * nc).astype(np.int32) + off_n).to(cuda)
+        kids[::97] = -1
+        segs.append({'head_ids': heads, 'child_ids': kids, 'n_heads': n_heads, 'n_child': nc})
+        xs = kernels.gather_rows(t_self, heads, off_s)
+        xm = kernels.gather_mean(t_neigh, kids, n_heads, nc, off_n)
+        want.append(kernels.sage_project(xs, xm, f32(ws), f32(wn), f32(bias), 'relu'))
+    want = torch.cat(want)
+    rows = want.shape[0]
+    save_s, save_m = torch.empty((rows, fs), device=cuda), torch.empty((rows, fn), device=cuda)
+    got = kernels.sage_fused(t_self, off_s, t_neigh, off_n, segs, f32(ws), f32(wn), f32(bias), 'relu',
+                             save_self=save_s, save_mean=save_m)
+    close(got, want, scale=float(want.abs().max()))
+    # rows of the first tiles, a tile border in the middle, and the tail against the float64 restatement
+    pick = torch.cat([torch.arange(0, 200), torch.arange(128 * 257 - 20, 128 * 257 + 20), torch.arange(rows - 400, rows)])
+    heads_all = torch.cat([s_['head_ids'] for s_ in segs]).cpu().numpy()
+    ts, tn = t_self.cpu().numpy().astype(np.float64), t_neigh.cpu().numpy().astype(np.float64)
+    start = 0
+    for s_ in segs:
+        nh, nc = s_['n_heads'], s_['n_child']
+        sel = pick[(pick >= start) & (pick < start + nh)].numpy() - start
+        if len(sel):
+            hid = s_['head_ids'].cpu().numpy()[sel] - off_s
+            kid = s_['child_ids'].cpu().numpy().reshape(nh, nc)[sel] - off_n
+            ok = (kid >= 0) & (kid < n_neigh)
+            xn = np.where(ok[..., None], tn[np.clip(kid, 0, n_neigh - 1)], 0.0)
+            o = omodel.aggregator(torch.from_numpy(ts[hid])[:, None, :], torch.from_numpy(xn)[:, None], ws, wn, bias, 'relu')[:, 0, :]
+            close(got[start + sel], o, scale=float(o.abs().max()))
+            np.testing.assert_array_equal(save_s[start + sel].cpu().numpy(), ts[hid].astype(np.float32))
+            close(save_m[start + sel], torch.from_numpy(xn.mean(1)), scale=1.0)
+        start += nh
 
 
 @pytest.mark.parametrize('ns,sizes,fu,fi', [([8, 4], [32, 32], 64, 64), ([25, 10], [32, 32], 64, 32),
-                                            ([4, 3, 2], [32, 64, 32], 32, 64), ([8, 4], [32, 32], 24, 19)])
+                                            ([4, 3, 2], [32, 64, 32], 32, 64), ([8, 4], [32, 32], 24, 19),
+                                            ([5, 3, 2], [256, 256, 256], 64, 128)])     # wide layers: wide kernel
 def test_engine_fused_and_unfused_match_model_and_oracle(cuda, ns, sizes, fu, fi):
     from graphsage_amd.engine import SageForwardEngine
     rng = np.random.default_rng(3)
