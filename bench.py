@@ -147,6 +147,11 @@ def result_line(args, cfg, engine, world, b, fwd, train, cpu):
                      "unit": "GB/s", "frac": achieved / 8000.0, "traffic": engine.measured_traffic(args.workload),
                      "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes, "launches_timed": len(dom_ms)},
     }
+    flops = engine.dominant_flops()
+    if flops and dom_avg > 0:
+        # wide layers: the same launch is also priced against the fp32 matrix peak (157 TFLOP/s dense)
+        out["roofline"]["mfma"] = {"achieved": flops / dom_avg / 1e12, "peak": 157.0, "unit": "TFLOP/s",
+                                   "frac": flops / dom_avg / 1e12 / 157.0, "flops_per_launch": flops}
     if train is not None:
         out["train_step"] = train
     if cpu is not None:

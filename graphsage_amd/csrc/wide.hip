@@ -7,18 +7,22 @@
 // each output half it accumulates a 128x128 fp32 product over k slices of 32:
 // first the own rows against W_self, then the neighbor means against W_neigh.
 //
-//   producer waves   per k slice: the 128 x 32 operand slice -- for the neighbor
+//   producer waves   eight waves.  Per k slice the 128 x 32 operand slice: for the neighbor
 //                    half the n_child rows of every head are summed as they arrive,
-//                    16 bytes per lane, eight lanes per row, and divided by n_child;
+//                    16 bytes per lane, eight lanes per row, and scaled by 1/n_child;
 //                    the own-row half is the same code with one "child", the head
-//                    itself -- plus the 32 x 128 weight slice, written into one of
-//                    two LDS stages in MFMA fragment order.  A thread keeps the
-//                    loads of two slices in flight: while slice s is multiplied,
-//                    slice s+1 moves from registers to LDS and the loads of slice
-//                    s+3 are issued behind those of s+2.
+//                    itself.  The slice goes into one of two LDS stages in MFMA
+//                    fragment order.  A thread keeps the loads of two slices in
+//                    flight: while slice s is multiplied, slice s+1 moves from
+//                    registers to LDS and the loads of slice s+3 are issued behind
+//                    those of s+2.  These loads are issued and waited for by hand
+//                    (see load16_async): the compiler's own bookkeeping turns every
+//                    wait into a wait for all loads in flight.
 //   consumer waves   four waves, each a 64x64 quarter of the tile: one
 //                    ds_read_b128 per 16x16 fragment feeds four
-//                    v_mfma_f32_16x16x4_f32; bias, activation and 16-byte row
+//                    v_mfma_f32_16x16x4_f32.  They also fetch the 32 x 128 weight
+//                    slice of the next k slice before the multiply and put it into
+//                    the other LDS stage after it.  Bias, activation and 16-byte row
 //                    stores go through a wave-private LDS patch.
 //
 // All waves meet at one barrier per k slice.  Row ids of a tile (node id - table
@@ -59,6 +63,8 @@ struct Cursor {
     int tile;           // global tile index (tiles of 128 heads: 32 bits hold any count the host accepts)
     int local;          // index among this block's tiles (parity picks the id buffer)
     int ct, side, ks;   // column tile, 0 own rows / 1 neighbor means, k slice
+    int n_child;        // children per head in the tile's segment; looked up when the tile changes, so that
+    float inv;          // a slice costs no scalar loads (their round trips were on every slice's critical path)
 };
 
 struct Shape {
@@ -66,17 +72,6 @@ struct Shape {
     int ns, nn, nct;    // k slices per half, column tiles per half
     int stride;         // tiles between two tiles of one block
 };
-
-__device__ __forceinline__ void advance(Cursor &c, const Shape &sh) {
-    if (++c.ks < (c.side ? sh.nn : sh.ns)) return;
-    c.ks = 0;
-    if (++c.side < 2) return;
-    c.side = 0;
-    if (++c.ct < sh.nct) return;
-    c.ct = 0;
-    c.tile += sh.stride;
-    ++c.local;
-}
 
 // (uniform values are kept to 32 bits where they are compared: the scalar unit has no ordered 64-bit
 // compare, and the vector compare the compiler falls back to needs temporaries in vector registers)
@@ -86,6 +81,23 @@ __device__ __forceinline__ int find_seg(const FusedArgs &a, int tile) {
     for (int s = 1; s < kMaxSegs; ++s)
         if (s < a.n_segs && tile >= (int)a.seg[s].tile0) si = s;
     return __builtin_amdgcn_readfirstlane(si);       // a scalar: a.seg[si] is then read with scalar loads
+}
+
+__device__ __forceinline__ void enter_tile(Cursor &c, const FusedArgs &a) {
+    c.n_child = a.seg[find_seg(a, c.tile)].n_child;
+    c.inv = 1.0f / (float)c.n_child;
+}
+
+__device__ __forceinline__ void advance(Cursor &c, const Shape &sh, const FusedArgs &a) {
+    if (++c.ks < (c.side ? sh.nn : sh.ns)) return;
+    c.ks = 0;
+    if (++c.side < 2) return;
+    c.side = 0;
+    if (++c.ct < sh.nct) return;
+    c.ct = 0;
+    c.tile += sh.stride;
+    ++c.local;
+    enter_tile(c, a);
 }
 
 // ---- producer -----------------------------------------------------------------
@@ -205,7 +217,7 @@ struct Producer {
 
     // loads of one slice: all chunks of children but the last are summed here, the last stays in flight
     __device__ __forceinline__ void begin(Slice &s, const Cursor &c) {
-        const int n = c.side ? a.seg[find_seg(a, c.tile)].n_child : 1;
+        const int n = c.side ? c.n_child : 1;
         const int F = c.side ? sh.Fn : sh.Fs;
         const unsigned long long b64 = reinterpret_cast<unsigned long long>(c.side ? a.feat_neigh : a.feat_self) + (size_t)c.ks * (WK * 4);
         const char *__restrict__ base = reinterpret_cast<const char *>(                      // uniform: in scalar registers
@@ -223,7 +235,7 @@ struct Producer {
             accumulate(s);
         }
         load_chunk<true>(s, base, fb, rows, n, (nch - 1) * CH, n - (nch - 1) * CH);
-        s.inv = 1.0f / (float)n;
+        s.inv = c.side ? c.inv : 1.0f;
     }
 
     // the slice in flight: last chunk added, mean taken, both operand slices written to LDS stage `buf`
@@ -307,12 +319,13 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     if (tid >= kConsumerThreads) {
         Producer<NPT, CH, BIG> pr(a, sh, st, hrow, crow, tid - kConsumerThreads, tid - kConsumerThreads);
         typename Producer<NPT, CH, BIG>::Slice s0, s1;             // slices of even / odd index
-        Cursor cl{(int)blockIdx.x, 0, 0, 0, 0};              // next slice to load
+        Cursor cl{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f};      // next slice to load
+        enter_tile(cl, a);
         Cursor cc = cl;                                            // slice the consumers multiply
         int gl = 0;                                                // index of cl; past the last slice it stays there
         // (the surplus loads and LDS writes at the end are harmless and keep the loop free of branches
         // around loads, which is what lets a wait for one slice leave the next one in flight)
-#define WD_NEXT() { if (gl + 1 < T) { advance(cl, sh); ++gl; } }
+#define WD_NEXT() { if (gl + 1 < T) { advance(cl, sh, a); ++gl; } }
         pr.ids_issue(cl.tile);
         pr.ids_commit(cl.tile, 0);
         block_sync();
@@ -325,39 +338,18 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         // (its loads were issued two barriers ago), then the freed registers take the loads of slice g+3.
 #define WD_TICK(S_, buf_)                                                                           \
         {                                                                                           \
-            const int next_tile = cc.tile + sh.stride;                                        \
+            const int next_tile = cc.tile + sh.stride;                                              \
             const bool stage_ids = cc.ct == 0 && cc.side == 0 && cc.ks == 0 && next_tile < n_tiles; \
-            WD_STAMP(t0)                                                                            \
             pr.finish(S_, buf_);                                                                    \
-            WD_STAMP(t1)                                                                            \
             pr.begin(S_, cl); WD_NEXT()                                                             \
             if (stage_ids) { pr.ids_issue(next_tile); pr.ids_commit(next_tile, (cc.local + 1) & 1); } \
-            advance(cc, sh);                                                                        \
-            WD_STAMP(t2)                                                                            \
-            block_sync();                                                                        \
-            WD_STAMP(t3)                                                                            \
-            WD_SUM()                                                                                \
+            advance(cc, sh, a);                                                                     \
+            block_sync();                                                                           \
         }
-#ifdef WD_EXP_TIMING
-        unsigned long long tp_fin = 0, tp_beg = 0, tp_bar = 0;
-#define WD_STAMP(t_) __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = wall_clock64(); __builtin_amdgcn_sched_barrier(0);
-#define WD_SUM() tp_fin += t1 - t0; tp_beg += t2 - t1; tp_bar += t3 - t2;
-#else
-#define WD_STAMP(t_)
-#define WD_SUM()
-#endif
         for (int g = 0; g < T; g += 2) {
             WD_TICK(s1, 1)
             if (g + 1 < T) WD_TICK(s0, 0)
         }
-#ifdef WD_EXP_TIMING
-        if (blockIdx.x == 0 && (tid == kConsumerThreads || tid == kConsumerThreads + 256)) {
-            float *d = a.save_self + (tid == kConsumerThreads ? 4 : 8);
-            d[0] = (float)tp_fin; d[1] = (float)tp_beg; d[2] = (float)tp_bar; d[3] = (float)T;
-        }
-#endif
-#undef WD_STAMP
-#undef WD_SUM
 #undef WD_TICK
 #undef WD_NEXT
         return;
@@ -464,57 +456,32 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         *reinterpret_cast<float4 *>(Bw + WD_B_DST(3)) = bw3;                                           \
     }
 
-    Cursor c{(int)blockIdx.x, 0, 0, 0, 0}, done = c;
+    Cursor c{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f}, done = c;
     bool pending = false;
     block_sync();
     WD_LOAD_B(c);
     WD_STORE_B(0);
     Cursor cn = c;                                                  // the slice after c
-    advance(cn, sh);
+    advance(cn, sh, a);
     block_sync();
-#ifdef WD_EXP_TIMING
-    unsigned long long tc_epi = 0, tc_mma = 0, tc_bar = 0;
-#endif
     for (int g = 0; g < T; ++g) {
-#ifdef WD_EXP_TIMING
-        const unsigned long long t0 = wall_clock64();
-#endif
         if (pending) epilogue(done);
-#ifdef WD_EXP_TIMING
-        const unsigned long long t1 = wall_clock64();
-#endif
         const float *S = st + (int)(g & 1) * 2 * W_TILE;
         if (g + 1 < T) WD_LOAD_B(cn);
         __builtin_amdgcn_sched_barrier(0);
-#ifndef WD_EXP_NOMFMA
         WD_READ(X, S, 0, a_slot0);
         WD_MFMA(X);
         WD_READ(X, S, 1, a_slot1);
         WD_MFMA(X);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if (g + 1 < T) WD_STORE_B((int)((g + 1) & 1));
-        advance(cn, sh);
+        advance(cn, sh, a);
         pending = c.ks + 1 == (c.side ? sh.nn : sh.ns);
         done = c;
-        advance(c, sh);
-#ifdef WD_EXP_TIMING
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long t2 = wall_clock64();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        advance(c, sh, a);
         block_sync();
-#ifdef WD_EXP_TIMING
-        const unsigned long long t3 = wall_clock64();
-        tc_epi += t1 - t0; tc_mma += t2 - t1; tc_bar += t3 - t2;
-#endif
     }
     if (pending) epilogue(done);
-#ifdef WD_EXP_TIMING
-    if (blockIdx.x == 0 && tid == 0) {
-        a.save_self[0] = (float)tc_epi; a.save_self[1] = (float)tc_mma; a.save_self[2] = (float)tc_bar; a.save_self[3] = (float)T;
-    }
-#endif
 #undef WD_READ
 #undef WD_LOAD_B
 #undef WD_B_COL

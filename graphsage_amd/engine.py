@@ -306,8 +306,22 @@ class SageForwardEngine:
         if self.walk_kernel:
             return "sage2_kernel (sample + both layers + l2norm, one wavefront per walk)"
         if self.use_fused and all(self.fused_layers):
+            if self.wide_first_layer_only:
+                return ("sage_wide_kernel (layer 0: neighbor gather + mean on producer waves beside the MFMA "
+                        "projection, one launch per node type)")
             return "sage_fused_kernel (layer 0: gather + neighbor mean + projection, one launch per node type)"
         return "gather_mean_kernel (deepest hop: rows summed as fetched)"
+
+    def dominant_flops(self):
+        """Multiply-add flops of ONE launch of the dominant kernel where it is a
+        matrix product worth pricing (the wide layer-0 kernel: average of the two
+        node types' launches); None otherwise."""
+        if not (self.use_fused and all(self.fused_layers) and self.wide_first_layer_only) or self.walk_kernel:
+            return None
+        f = self.graph.node_feature_sizes
+        per_type = [sum(n for (_, _, _, _, n) in self.segments[t]) * (f[t] + f[self.other[t]]) * self.model.dims[1][t]
+                    for t in _TYPES]                     # rows * (Fs + Fn) * H/2 * 2
+        return sum(per_type) / len(per_type)
 
     def dominant_bytes(self):
         """Algorithmic bytes of ONE launch of the deepest-hop gather-mean: child
@@ -351,6 +365,8 @@ class SageForwardEngine:
         with open(path) as fh:
             rec = json.load(fh)
         name = "sage_fused_kernel" if self.use_fused and all(self.fused_layers) else "gather_mean_kernel"
+        if name == "sage_fused_kernel" and self.wide_first_layer_only:
+            name = "sage_wide_kernel"
         if self.walk_kernel:
             name = "sage2_kernel"
         key = "%s/%s/B%d/%s" % (workload, name, self.batch, 'x'.join(str(n) for n in self.fanouts))

@@ -240,6 +240,13 @@ int gs_l2_normalize_bwd(const float *x, const float *g_out, int64_t M, int H,
  * gathered own rows and neighbor means (what the backward pass needs).
  * Supported shapes: gs_sage_fused_supported(Fs, Fn, H, max n_child) != 0;
  * otherwise GS_ELIMIT is returned and the three separate entry points apply.
+ * Two kernels stand behind this entry point: narrow layers (widths 32/64/128,
+ * H/2 of 16 or 32) keep all weights in LDS and give a wavefront 16 heads at a
+ * time; wide layers (widths multiples of 32 and at least 64, H/2 a multiple of
+ * 128, n_child <= 32) are tiled 128 heads x 128 columns with the gathers on
+ * their own wavefronts beside the matrix product.  For wide layers the save_*
+ * copies are made by the gather kernels before the layer runs, and normalize
+ * runs as a second small kernel on out.
  */
 typedef struct gs_fused_segment {
     const int32_t *head_ids;

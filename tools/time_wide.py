@@ -21,10 +21,8 @@ ws = torch.randn((f, h // 2), device=dev, generator=g) * 0.05
 wn = torch.randn((f, h // 2), device=dev, generator=g) * 0.05
 bias = torch.zeros(h, device=dev)
 out = torch.empty((heads, h), device=dev)
-import os
-dbg = torch.zeros((heads, f), device=dev) if os.environ.get('WIDE_TIMING') else None
 call = kernels.FusedLayerCall(t_self, 0, t_neigh, 0, [{'head_ids': hid, 'child_ids': cid, 'n_heads': heads, 'n_child': n_child}],
-                              ws, wn, bias, 'relu', False, out, save_self=dbg)
+                              ws, wn, bias, 'relu', False, out)
 for _ in range(3):
     call.run()
 torch.cuda.synchronize()
@@ -36,8 +34,3 @@ us = sorted(t.elapsed_us() for t in ts)[len(ts) // 2]
 flops = heads * f * (h // 2) * 2 * 2
 byts = heads * (1 + n_child) * f * 4 + heads * h * 4
 print("heads %d n_child %d table %d rows: %.1f us  %.1f TFLOP/s  %.2f TB/s algorithmic" % (heads, n_child, rows, us, flops / us * 1e-6, byts / us * 1e-6))
-if dbg is not None:
-    d = dbg.flatten()[:12].tolist()
-    T = d[3]
-    print("  block 0, per slice (x10 ns): consumer epilogue %.0f  multiply %.0f  barrier %.0f | producers even: finish %.0f begin %.0f barrier %.0f | odd: %.0f %.0f %.0f  (slices %d)"
-          % (d[0] / T, d[1] / T, d[2] / T, d[4] / T, d[5] / T, d[6] / T, d[8] / T, d[9] / T, d[10] / T, T))
