@@ -86,16 +86,21 @@ def cpu_baseline(graph, cfg, heads_u, heads_i, model, n_batches, batch=100):
     threads = torch.get_num_threads()
     torch.set_num_threads(1)
 
-    def one_pass():
+    def one_pass(n):
         random.seed(12345)
         t0 = time.perf_counter()
-        for k in range(n_batches):
+        for k in range(n):
             xs = ogen.sample_features_faithful(og, cfg['fan'], links[k * batch:(k + 1) * batch], random)
             omodel.forward(plan, weights, [torch.from_numpy(np.ascontiguousarray(x)) for x in xs])
         return time.perf_counter() - t0
 
-    one_pass()                       # fills the neighbor-list cache (the reference holds plain lists)
-    dt = one_pass()
+    # bounded sample: as many batches as fit in about 12 s (wide or deep workloads take seconds per batch)
+    t_first = one_pass(1)
+    n_batches = max(2, min(n_batches, int(12.0 / max(t_first, 1e-3))))
+    print("[bench] cpu baseline: %.2f s for the first batch, timing %d batches" % (t_first, n_batches),
+          file=sys.stderr, flush=True)
+    one_pass(n_batches)              # fills the neighbor-list cache (the reference holds plain lists)
+    dt = one_pass(n_batches)
 
     # the same work written the way a CPU likes it: numpy-vectorised Philox walk over the CSR,
     # fancy-index gathers, torch matmuls on this process's share of the cores
@@ -105,14 +110,20 @@ def cpu_baseline(graph, cfg, heads_u, heads_i, model, n_batches, batch=100):
     indptr, indices = dev['indptr'].cpu().numpy(), dev['indices'].cpu().numpy()
     vb = 1024
     v_batches = max(1, min(8, len(links) // vb))
+    print("[bench] cpu baseline: vectorised pass", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
+    done = 0
     for k in range(v_batches):
+        if done and time.perf_counter() - t0 > 10.0:      # bounded, like the single-thread sample
+            break
+        done += 1
         part = links[k * vb:(k + 1) * vb]
         roots = np.asarray([l[0] for l in part] + [l[1] for l in part], dtype=np.int64)
         hops = walker.walk_vectorised(indptr, indices, roots, cfg['fan'], rng_seed=1, first_walk=2 * k * vb)
         xs = ogen.sample_features_fast(feats, graph.num_users, part, hops)
         omodel.forward(plan, weights, [torch.from_numpy(np.ascontiguousarray(x)) for x in xs])
     dv = time.perf_counter() - t0
+    v_batches = done
     torch.set_num_threads(threads)
     return {"value": n_batches * batch / dt, "unit": "seed edges/s", "cores": 1, "kind": "port",
             "sample": "%d batches x %d seed edges (the reference script's batch size), same graph and fan-outs; "
