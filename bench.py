@@ -134,6 +134,47 @@ def cpu_baseline(graph, cfg, heads_u, heads_i, model, n_batches, batch=100):
                                      "forward, %.1f s" % (v_batches, vb, dv)}}
 
 
+def autograd_train_step(args, ga, gen, model, heads_u, heads_i, b, rank, world, dist, sync_dev, device, why):
+    """Training step for shapes the static plan does not cover (wide layers): batch build through
+    flow(), the model through torch.autograd Functions over the general kernels, flat-bucket
+    all-reduce, Adam.  A handful of steps (each costs tens of milliseconds)."""
+    import numpy as np
+    import torch
+    from graphsage_amd.train import Trainer
+    try:
+        steps = max(2, min(args.train_steps, 5))
+        n_b = (2 + steps) * world
+        hu, hi = heads_u[:n_b * b].tolist(), heads_i[:n_b * b].tolist()
+        seq = gen.flow(list(zip(hu, hi)), targets=(np.arange(n_b * b) % 2).astype(np.float32))
+        tr = Trainer(model, lr=1e-2, engine='autograd')
+        mine = list(range(rank, n_b, world))
+
+        def tstep(i):
+            batch, y = seq[mine[i]]
+            return tr.step(batch, torch.as_tensor(np.asarray(y, dtype=np.float32), device=device))
+
+        for i in range(2):
+            tstep(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            tstep(2 + i)
+        torch.cuda.synchronize()
+        t_el = time.perf_counter() - t1
+        if world > 1:
+            dist.barrier()
+            tt = torch.tensor([t_el], dtype=torch.float64, device=sync_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_el = float(tt.item())
+        return {"value": steps * b * world / t_el, "unit": "seed edges/s", "ms_per_step": t_el / steps * 1e3,
+                "steps": steps, "what": "flow() batch build + fwd + bwd through autograd over the general kernels + "
+                                        "flat-bucket all-reduce + Adam; " + why}
+    except Exception as ex:
+        return {"skipped": "%s; autograd path: %s" % (why, str(ex)[:160])}
+
+
 def result_line(args, cfg, engine, world, b, fwd, train, cpu):
     """The one JSON line rank 0 prints."""
     elapsed = fwd["elapsed"]
@@ -271,7 +312,8 @@ def main():
             tr = Trainer(model, lr=1e-2, engine='plan', graph=graph, batch_size=b)
         except Exception as ex:                              # shapes outside the static plan
             tr = None
-            train = {"skipped": str(ex)[:200]}
+            train = autograd_train_step(args, ga, gen, model, heads_u, heads_i, b, rank, world, dist, sync_dev, device,
+                                        "static plan not available (%s)" % str(ex)[:120])
         if tr is not None:
             tgt = (torch.arange(b, device=device) % 2).to(torch.float32)
 
