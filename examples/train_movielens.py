@@ -29,7 +29,8 @@ def main():
     ap.add_argument('--layer-sizes', type=int, nargs='+', default=[32, 32])  # :175
     ap.add_argument('--epochs', type=int, default=1)                 # :192
     ap.add_argument('--lr', type=float, default=1e-2)                # :185
-    ap.add_argument('--pad-features', type=int, default=32, help='0 keeps the raw widths (general kernels)')
+    ap.add_argument('--pad-features', type=int, default=0,
+                    help='pad the feature tables to a multiple of this at load time (0: raw widths; the engines pad internally)')
     ap.add_argument('--reference-feature-order', action='store_true',
                     help="keep feature rows in file order as the reference's script does")
     ap.add_argument('--seed', type=int, default=0)

@@ -20,6 +20,18 @@ from .engine import SageForwardEngine, _TYPES
 
 class SageTrainEngine(SageForwardEngine):
     def __init__(self, graph, model, batch_size):
+        # Feature widths that are not multiples of 32 (MovieLens: 28 / 18 columns) run through zero-padded
+        # copies of the tables and of the layer-0 weights; the real weights and their gradients are copied
+        # in and out around every pass (padding.py).
+        self._padded_model = None
+        f = graph.node_feature_sizes
+        if any(f[t] % 32 for t in _TYPES):
+            from .padding import PaddedGraphView, PaddedModelView, padded_widths
+            wide = padded_widths(f)
+            if all(kernels.fused_supported(wide[t], wide['item' if t == 'user' else 'user'], model.build().dims[1][t],
+                                           max(model.n_samples)) for t in _TYPES):
+                graph = PaddedGraphView(graph, wide)
+                model = self._padded_model = PaddedModelView(model, wide)
         super().__init__(graph, model, batch_size, use_fused=True, walk_kernel=False)
         if self.agg_max:
             raise kernels._lib.GsageError("the training plan covers the mean aggregator; agg_option='max' trains "
@@ -101,6 +113,8 @@ class SageTrainEngine(SageForwardEngine):
     def forward_train(self, seeds, walk_ids=None, rng_seed=0, replay=None):
         """Returns the (user, item) embeddings; every intermediate the backward
         pass needs stays in the engine's buffers."""
+        if self._padded_model is not None:
+            self._padded_model.refresh()
         if self.walk_train:
             return self._forward_walks_train(seeds, walk_ids, rng_seed, replay)
         self.sample(seeds, walk_ids, rng_seed, replay)
@@ -195,3 +209,5 @@ class SageTrainEngine(SageForwardEngine):
                             # else: the projection backward wrote the roots' rows in place
             g_out = {t: g_prev[t] for t in _TYPES}
         main.wait_stream(self._side)
+        if self._padded_model is not None:
+            self._padded_model.scatter_grads()

@@ -99,14 +99,16 @@ def test_short_run_learns(cuda):
 
 @pytest.mark.parametrize('ns,sizes,f', [([8, 4], [32, 32], 64), ([5, 3, 2], [32, 64, 32], 32), ([25, 10], [32, 32], 64),
                                         ([3, 2], [32, 32], 128), ([10, 5], [64, 32], 32), ([7], [32], 64),
-                                        ([2, 2, 2, 2], [32, 32, 32, 32], 32), ([12, 1], [32, 64], 64)])
+                                        ([2, 2, 2, 2], [32, 32, 32, 32], 32), ([12, 1], [32, 64], 64),
+                                        ([8, 4], [32, 32], (24, 19)), ([5, 3, 2], [32, 64, 32], (28, 18))])
 def test_plan_engine_step_equals_autograd_step(cuda, ns, sizes, f):
     """The static training plan (fused forward with saved activations + kernel
     backward) produces the same loss, gradients and updated weights as the
     autograd path on the same sampled batch."""
-    g, links, targets = _toy(3, fu=f, fi=f)
+    # (odd widths, the last two cases: the plan runs on zero-padded tables and layer-0 weights)
+    fu, fi = f if isinstance(f, tuple) else (f, f)
+    g, links, targets = _toy(3, fu=fu, fi=fi)
     b = 48
-    import copy
     results = []
     for engine in ('autograd', 'plan'):
         gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
@@ -138,6 +140,11 @@ def test_plan_engine_step_equals_autograd_step(cuda, ns, sizes, f):
     assert float((g0 - g1).abs().max()) <= 2e-5 * scale
     for a, c in zip(p0, p1):
         assert float((a - c).abs().max()) < 2e-4
+    if isinstance(f, tuple):                        # the copies in and out of the padded weights replay from a graph too
+        before = [p.detach().clone() for p in tr.params]
+        loss_g, _ = tr.step_graph(seeds, t, walk_ids, rng_seed=77)
+        assert np.isfinite(float(loss_g)) and float(loss_g) < l1 + 1e-3
+        assert any(float((a - c).abs().max()) > 0 for a, c in zip(before, tr.params))
 
 
 def test_link_head_kernel_and_adam_kernel(cuda):
