@@ -36,12 +36,11 @@ class SageTrainEngine(SageForwardEngine):
         if self.agg_max:
             raise kernels._lib.GsageError("the training plan covers the mean aggregator; agg_option='max' trains "
                                           "through graphsage_amd.train.Trainer(engine='autograd')")
-        narrow = all(model.dims[layer + 1][t] // 2 in (16, 32) and model.dims[layer][t] <= 128
-                     for layer in range(self.n_hops) for t in _TYPES)
-        if not all(self.fused_layers) or not narrow:       # (wide layers have a fused forward kernel only)
+        if not all(self.fused_layers):
             raise kernels._lib.GsageError(
-                "the training plan needs the fused layer kernel (feature and hidden widths in {32, 64, 128}, "
-                "half-widths 16 or 32); use graphsage_amd.train.Trainer(engine='autograd') for other shapes")
+                "the training plan needs a fused layer kernel for every layer (widths 32/64/128 with half-widths 16 "
+                "or 32, or multiples of 32 with half-widths that are multiples of 128); use "
+                "graphsage_amd.train.Trainer(engine='autograd') for other shapes")
         m = self.model
         dev = self.indptr.device
         new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=dev)
