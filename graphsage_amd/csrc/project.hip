@@ -507,6 +507,167 @@ void wgrad_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk,
     if (bias_block && wave == 0 && col0 + lane < N) slab[(int64_t)K * N + col0 + lane] = bsum;
 }
 
+// Weight gradient of wide layers (K and N multiples of 128): a block forms a 128 x 128 tile of
+// dW = X^T G over its chunk of rows on the four-wave 64x64 MFMA scheme of rows_gemm_big_kernel.
+// The row index m is the reduction index here, so BOTH operands sit in LDS the way that kernel
+// keeps its weight tile: for each column, four consecutive m adjacent, one ds_read_b128 per 16x16
+// fragment feeding four MFMAs.  A thread fetches a 4 row x 4 column patch of X and of G (four
+// 16-byte loads each) and writes it out transposed, so nothing is loaded twice and no load is
+// narrower than 16 bytes.  Same slab layout and reduction as wgrad_kernel (bitwise reproducible).
+constexpr int WB_ROWS = 32;                               // rows of M per slice
+constexpr int WB_TILE = WB_ROWS * 128;                    // floats of one operand slice
+constexpr size_t WB_LDS = size_t(4) * WB_TILE * sizeof(float);   // X and G, two stages each
+
+__global__ __launch_bounds__(kThreads, 2)
+void wgrad_big_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk) {
+    extern __shared__ __align__(16) float wb_smem[];
+    const int tiles0 = (s0.K / 128) * (s0.N / 128);
+    const bool second = (int)blockIdx.y >= tiles0;
+#define GS_SEL(f) (second ? s1.f : s0.f)
+    const float *__restrict__ X = GS_SEL(X);
+    const float *__restrict__ G = GS_SEL(G);
+    const float *__restrict__ Mk = GS_SEL(mask);
+    float *__restrict__ slab_base = GS_SEL(slab);
+    const int K = GS_SEL(K), N = GS_SEL(N), ldg = GS_SEL(ldg);
+#undef GS_SEL
+    const int ncb = N / 128;
+    const int tile = (int)blockIdx.y - (second ? tiles0 : 0);
+    const int kb0 = (tile / ncb) * 128, col0 = (tile % ncb) * 128;
+    const int64_t chunk = blockIdx.x;
+    const int64_t m_begin = chunk * rows_per_chunk;
+    const int64_t m_end = min(M, m_begin + rows_per_chunk);      // > m_begin: the grid has no empty chunks
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wave_m = wave & 1, wave_n = wave >> 1;
+    const bool bias_block = kb0 == 0;                            // this block also forms the column sums
+
+    // loader role: rows 4 mq .. 4 mq + 3 of the slice, columns 4 cq .. 4 cq + 3 of the tile
+    const int mq = tid >> 5, cq = tid & 31;
+    const int dst0 = ((mq >> 2) * 8 + (cq >> 2)) * 256 + ((mq & 3) * 16 + (cq & 3) * 4) * 4;
+    const float *__restrict__ xp = X + kb0 + cq * 4;
+    const float *__restrict__ gp = G + col0 + cq * 4;
+    const float *__restrict__ kp = Mk ? Mk + col0 + cq * 4 : nullptr;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);                 // column sums of this thread's patch rows
+    float4 x0, x1, x2, x3, g0, g1, g2, g3;
+
+#define WB_LOAD_ROW(xr_, gr_, e_)                                                                   \
+    {                                                                                               \
+        const int64_t m = m0 + mq * 4 + (e_);                                                       \
+        const bool live = m < m_end;                                                                \
+        const int64_t mc = live ? m : m_end - 1;                /* rows past the end: loaded, zeroed */ \
+        xr_ = *reinterpret_cast<const float4 *>(xp + mc * K);                                       \
+        gr_ = *reinterpret_cast<const float4 *>(gp + mc * ldg);                                     \
+        if (kp) {                                                                                   \
+            const float4 mk = *reinterpret_cast<const float4 *>(kp + mc * ldg);                     \
+            if (!(mk.x > 0.f)) gr_.x = 0.f;                                                         \
+            if (!(mk.y > 0.f)) gr_.y = 0.f;                                                         \
+            if (!(mk.z > 0.f)) gr_.z = 0.f;                                                         \
+            if (!(mk.w > 0.f)) gr_.w = 0.f;                                                         \
+        }                                                                                           \
+        if (!live) { xr_ = make_float4(0.f, 0.f, 0.f, 0.f); gr_ = xr_; }                            \
+    }
+#define WB_LOAD(m0_)                                                                                \
+    {                                                                                               \
+        const int64_t m0 = (m0_);                                                                   \
+        WB_LOAD_ROW(x0, g0, 0) WB_LOAD_ROW(x1, g1, 1) WB_LOAD_ROW(x2, g2, 2) WB_LOAD_ROW(x3, g3, 3) \
+    }
+#define WB_STORE(stage_)                                                                            \
+    {                                                                                               \
+        float *Xs = wb_smem + (stage_) * 2 * WB_TILE + dst0, *Gs = Xs + WB_TILE;                    \
+        *reinterpret_cast<float4 *>(Xs) = make_float4(x0.x, x1.x, x2.x, x3.x);                      \
+        *reinterpret_cast<float4 *>(Xs + 4) = make_float4(x0.y, x1.y, x2.y, x3.y);                  \
+        *reinterpret_cast<float4 *>(Xs + 8) = make_float4(x0.z, x1.z, x2.z, x3.z);                  \
+        *reinterpret_cast<float4 *>(Xs + 12) = make_float4(x0.w, x1.w, x2.w, x3.w);                 \
+        *reinterpret_cast<float4 *>(Gs) = make_float4(g0.x, g1.x, g2.x, g3.x);                      \
+        *reinterpret_cast<float4 *>(Gs + 4) = make_float4(g0.y, g1.y, g2.y, g3.y);                  \
+        *reinterpret_cast<float4 *>(Gs + 8) = make_float4(g0.z, g1.z, g2.z, g3.z);                  \
+        *reinterpret_cast<float4 *>(Gs + 12) = make_float4(g0.w, g1.w, g2.w, g3.w);                 \
+        bs.x += ((g0.x + g1.x) + g2.x) + g3.x;                                                      \
+        bs.y += ((g0.y + g1.y) + g2.y) + g3.y;                                                      \
+        bs.z += ((g0.z + g1.z) + g2.z) + g3.z;                                                      \
+        bs.w += ((g0.w + g1.w) + g2.w) + g3.w;                                                      \
+    }
+    f32x4 aX0, aX1, aX2, aX3, bX0, bX1, bX2, bX3;
+#define WB_READ(stage_, half_)                                                                      \
+    {                                                                                               \
+        const float *As_r = wb_smem + (stage_) * 2 * WB_TILE + ((half_) * 8 + wave_m * 4) * 256 + lane * 4; \
+        const float *Bs_r = wb_smem + (stage_) * 2 * WB_TILE + WB_TILE + ((half_) * 8 + wave_n * 4) * 256 + lane * 4; \
+        aX0 = *reinterpret_cast<const f32x4 *>(As_r);                                               \
+        bX0 = *reinterpret_cast<const f32x4 *>(Bs_r);                                               \
+        aX1 = *reinterpret_cast<const f32x4 *>(As_r + 256);                                         \
+        bX1 = *reinterpret_cast<const f32x4 *>(Bs_r + 256);                                         \
+        aX2 = *reinterpret_cast<const f32x4 *>(As_r + 512);                                         \
+        bX2 = *reinterpret_cast<const f32x4 *>(Bs_r + 512);                                         \
+        aX3 = *reinterpret_cast<const f32x4 *>(As_r + 768);                                         \
+        bX3 = *reinterpret_cast<const f32x4 *>(Bs_r + 768);                                         \
+    }
+#define WB_MFMA_ROW(i_, av_, st_)                                                                   \
+    acc[i_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bX0[st_], acc[i_][0], 0, 0, 0);     \
+    acc[i_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bX1[st_], acc[i_][1], 0, 0, 0);     \
+    acc[i_][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bX2[st_], acc[i_][2], 0, 0, 0);     \
+    acc[i_][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bX3[st_], acc[i_][3], 0, 0, 0);
+#define WB_MFMA()                                                                                   \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                              \
+        WB_MFMA_ROW(0, aX0, st) WB_MFMA_ROW(1, aX1, st) WB_MFMA_ROW(2, aX2, st) WB_MFMA_ROW(3, aX3, st) \
+    }
+
+    const int n_slices = (int)((m_end - m_begin + WB_ROWS - 1) / WB_ROWS);
+    WB_LOAD(m_begin);
+    WB_STORE(0);
+    __syncthreads();
+    for (int kt = 0; kt < n_slices; ++kt) {
+        const int stage = kt & 1;
+        const bool more = kt + 1 < n_slices;
+        if (more) WB_LOAD(m_begin + (int64_t)(kt + 1) * WB_ROWS);   // in flight during the multiply
+        __builtin_amdgcn_sched_barrier(0);
+        WB_READ(stage, 0);
+        WB_MFMA();
+        WB_READ(stage, 1);
+        WB_MFMA();
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) WB_STORE(stage ^ 1);             // that stage was last read before the previous barrier
+        __syncthreads();
+    }
+#undef WB_LOAD_ROW
+#undef WB_LOAD
+#undef WB_STORE
+#undef WB_READ
+#undef WB_MFMA_ROW
+#undef WB_MFMA
+
+    float *slab = slab_base + chunk * (int64_t)(K + 1) * N;
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                slab[(int64_t)(kb0 + wave_m * 64 + i * 16 + q * 4 + e) * N + col0 + wave_n * 64 + j * 16 + r] = acc[i][j][e];
+    if (bias_block) {                              // eight threads hold partial sums of a column: added in row order
+        float *part = wb_smem;                     // [8][128]  (the loop ended with a barrier)
+        *reinterpret_cast<float4 *>(part + mq * 128 + cq * 4) = bs;
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += part[g * 128 + tid];
+            slab[(int64_t)K * N + col0 + tid] = t;
+        }
+    }
+}
+
+inline bool wgrad_big_applies(int Fs, int Fn, int Hh, int H, const void *xs, const void *xm, const void *g, const void *mask) {
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return Fs % 128 == 0 && Fn % 128 == 0 && Hh % 128 == 0 && H % 4 == 0 && al16(xs) && al16(xm) && al16(g) && (!mask || al16(mask));
+}
+
 // Adds the per-chunk slabs of both halves in one launch (blockIdx.y = half).  Element e is summed
 // by sixteen threads that take chunks c = j, j+16, ... each in increasing order; their partial
 // sums are then added in index order: the result does not depend on scheduling.
@@ -839,7 +1000,18 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
         float *slab0 = static_cast<float *>(workspace);
         float *slab1 = slab0 + (size_t)nc * (Fs + 1) * Hh;
         bool direct = false;
-        if (M > 0 && aligned16(x_self) && aligned16(x_mean) && aligned16(g_out) && (!mask || aligned16(mask))) {
+        if (M > 0 && wgrad_big_applies(Fs, Fn, Hh, H, x_self, x_mean, g_out, mask)) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_big_kernel),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS);
+            if (attr != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage_project_bwd: %s", hipGetErrorString(attr));
+            WgradSide a{}, b{};
+            a.X = x_self; a.G = g_out; a.mask = mask; a.slab = slab0; a.K = Fs; a.N = Hh; a.ldg = H;
+            b.X = x_mean; b.G = g_out + Hh; b.mask = mask ? mask + Hh : nullptr; b.slab = slab1; b.K = Fn; b.N = Hh; b.ldg = H;
+            const int by = (Fs / 128 + Fn / 128) * (Hh / 128);
+            hipLaunchKernelGGL(wgrad_big_kernel, dim3((unsigned)nc, (unsigned)by), dim3(kThreads), WB_LDS, s, a, b, M, rpc);
+            if (int rc = gs::check_launch("gs_sage_project_bwd (wgrad)")) return rc;
+            direct = true;                         // slabs written in the layout the reduction below expects
+        } else if (M > 0 && aligned16(x_self) && aligned16(x_mean) && aligned16(g_out) && (!mask || aligned16(mask))) {
             const int64_t rpb = wgrad_direct_rows(M);
             const int64_t nblocks = (M + rpb - 1) / rpb;          // <= nc: the slabs fit the workspace
             slab1 = slab0 + (size_t)nblocks * (Fs + 1) * Hh;

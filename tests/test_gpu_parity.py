@@ -341,7 +341,8 @@ def test_gather_mean_backward_scatter_add(cuda):
 
 SHAPES = [(213, 64, 64, 32), (200, 24, 19, 32), (200, 19, 24, 32), (1000, 32, 32, 32),
           (77, 256, 256, 256), (65, 30, 18, 6), (1, 64, 64, 32), (130, 7, 3, 2), (64, 64, 64, 160),
-          (700, 256, 256, 256), (1333, 64, 128, 256), (512, 32, 256, 512)]      # the last three take the 128x128-tile kernel
+          (700, 256, 256, 256), (1333, 64, 128, 256), (512, 32, 256, 512),      # these three take the 128x128-tile kernel
+          (5000, 128, 256, 256), (4100, 256, 128, 512), (31, 128, 128, 256)]    # and these its weight-gradient twin
 
 
 @pytest.mark.parametrize('m,fs,fn,h', SHAPES)
