@@ -541,9 +541,16 @@ void wgrad_big_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_ch
     const int wave_m = wave & 1, wave_n = wave >> 1;
     const bool bias_block = kb0 == 0;                            // this block also forms the column sums
 
-    // loader role: rows 4 mq .. 4 mq + 3 of the slice, columns 4 cq .. 4 cq + 3 of the tile
-    const int mq = tid >> 5, cq = tid & 31;
-    const int dst0 = ((mq >> 2) * 8 + (cq >> 2)) * 256 + ((mq & 3) * 16 + (cq & 3) * 4) * 4;
+    // loader role: rows 4 mq .. 4 mq + 3 of the slice, columns 4 cq .. 4 cq + 3 of the tile.  Sixteen
+    // consecutive lanes take 4 column quads x 4 row quads; with the 16-byte slots of a row quad rotated
+    // by the row quad's index their transposed writes (and the fragment reads, which undo the rotation)
+    // fall on sixteen different bank groups.
+    const int mq = (wave >> 1) * 4 + ((lane >> 2) & 3);
+    const int cq = (wave & 1) * 16 + ((lane >> 4) & 3) * 4 + (lane & 3);
+    const int blk0 = ((mq >> 2) * 8 + (cq >> 2)) * 256 + (mq & 3) * 64;
+    int dstf[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) dstf[f] = blk0 + (((cq & 3) * 4 + f + (mq & 3)) & 15) * 4;
     const float *__restrict__ xp = X + kb0 + cq * 4;
     const float *__restrict__ gp = G + col0 + cq * 4;
     const float *__restrict__ kp = Mk ? Mk + col0 + cq * 4 : nullptr;
@@ -556,48 +563,57 @@ void wgrad_big_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_ch
     float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);                 // column sums of this thread's patch rows
     float4 x0, x1, x2, x3, g0, g1, g2, g3;
 
-#define WB_LOAD_ROW(xr_, gr_, e_)                                                                   \
+    // A slice is only loaded here; the relu mask and the zeroing of rows past the end are applied when it
+    // is written to LDS, after the multiply of the slice before it: touching the values any earlier would
+    // put the wait for the loads in front of that multiply.
+    float4 k0 = make_float4(1.f, 1.f, 1.f, 1.f), k1 = k0, k2 = k0, k3 = k0;
+    int64_t m_loaded = m_begin;
+#define WB_LOAD_ROW(xr_, gr_, kr_, e_)                                                              \
     {                                                                                               \
         const int64_t m = m0 + mq * 4 + (e_);                                                       \
-        const bool live = m < m_end;                                                                \
-        const int64_t mc = live ? m : m_end - 1;                /* rows past the end: loaded, zeroed */ \
+        const int64_t mc = m < m_end ? m : m_end - 1;           /* rows past the end: loaded, zeroed later */ \
         xr_ = *reinterpret_cast<const float4 *>(xp + mc * K);                                       \
         gr_ = *reinterpret_cast<const float4 *>(gp + mc * ldg);                                     \
-        if (kp) {                                                                                   \
-            const float4 mk = *reinterpret_cast<const float4 *>(kp + mc * ldg);                     \
-            if (!(mk.x > 0.f)) gr_.x = 0.f;                                                         \
-            if (!(mk.y > 0.f)) gr_.y = 0.f;                                                         \
-            if (!(mk.z > 0.f)) gr_.z = 0.f;                                                         \
-            if (!(mk.w > 0.f)) gr_.w = 0.f;                                                         \
-        }                                                                                           \
-        if (!live) { xr_ = make_float4(0.f, 0.f, 0.f, 0.f); gr_ = xr_; }                            \
+        if (kp) kr_ = *reinterpret_cast<const float4 *>(kp + mc * ldg);                             \
     }
 #define WB_LOAD(m0_)                                                                                \
     {                                                                                               \
         const int64_t m0 = (m0_);                                                                   \
-        WB_LOAD_ROW(x0, g0, 0) WB_LOAD_ROW(x1, g1, 1) WB_LOAD_ROW(x2, g2, 2) WB_LOAD_ROW(x3, g3, 3) \
+        m_loaded = m0;                                                                              \
+        WB_LOAD_ROW(x0, g0, k0, 0) WB_LOAD_ROW(x1, g1, k1, 1) WB_LOAD_ROW(x2, g2, k2, 2) WB_LOAD_ROW(x3, g3, k3, 3) \
+    }
+#define WB_FIX_ROW(xr_, gr_, kr_, e_)                                                               \
+    {                                                                                               \
+        const bool live = m_loaded + mq * 4 + (e_) < m_end;                                         \
+        if (!(live && kr_.x > 0.f)) gr_.x = 0.f;                                                    \
+        if (!(live && kr_.y > 0.f)) gr_.y = 0.f;                                                    \
+        if (!(live && kr_.z > 0.f)) gr_.z = 0.f;                                                    \
+        if (!(live && kr_.w > 0.f)) gr_.w = 0.f;                                                    \
+        if (!live) xr_ = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
     }
 #define WB_STORE(stage_)                                                                            \
     {                                                                                               \
-        float *Xs = wb_smem + (stage_) * 2 * WB_TILE + dst0, *Gs = Xs + WB_TILE;                    \
-        *reinterpret_cast<float4 *>(Xs) = make_float4(x0.x, x1.x, x2.x, x3.x);                      \
-        *reinterpret_cast<float4 *>(Xs + 4) = make_float4(x0.y, x1.y, x2.y, x3.y);                  \
-        *reinterpret_cast<float4 *>(Xs + 8) = make_float4(x0.z, x1.z, x2.z, x3.z);                  \
-        *reinterpret_cast<float4 *>(Xs + 12) = make_float4(x0.w, x1.w, x2.w, x3.w);                 \
-        *reinterpret_cast<float4 *>(Gs) = make_float4(g0.x, g1.x, g2.x, g3.x);                      \
-        *reinterpret_cast<float4 *>(Gs + 4) = make_float4(g0.y, g1.y, g2.y, g3.y);                  \
-        *reinterpret_cast<float4 *>(Gs + 8) = make_float4(g0.z, g1.z, g2.z, g3.z);                  \
-        *reinterpret_cast<float4 *>(Gs + 12) = make_float4(g0.w, g1.w, g2.w, g3.w);                 \
+        WB_FIX_ROW(x0, g0, k0, 0) WB_FIX_ROW(x1, g1, k1, 1) WB_FIX_ROW(x2, g2, k2, 2) WB_FIX_ROW(x3, g3, k3, 3) \
+        float *Xs = wb_smem + (stage_) * 2 * WB_TILE, *Gs = Xs + WB_TILE;                           \
+        *reinterpret_cast<float4 *>(Xs + dstf[0]) = make_float4(x0.x, x1.x, x2.x, x3.x);            \
+        *reinterpret_cast<float4 *>(Xs + dstf[1]) = make_float4(x0.y, x1.y, x2.y, x3.y);            \
+        *reinterpret_cast<float4 *>(Xs + dstf[2]) = make_float4(x0.z, x1.z, x2.z, x3.z);            \
+        *reinterpret_cast<float4 *>(Xs + dstf[3]) = make_float4(x0.w, x1.w, x2.w, x3.w);            \
+        *reinterpret_cast<float4 *>(Gs + dstf[0]) = make_float4(g0.x, g1.x, g2.x, g3.x);            \
+        *reinterpret_cast<float4 *>(Gs + dstf[1]) = make_float4(g0.y, g1.y, g2.y, g3.y);            \
+        *reinterpret_cast<float4 *>(Gs + dstf[2]) = make_float4(g0.z, g1.z, g2.z, g3.z);            \
+        *reinterpret_cast<float4 *>(Gs + dstf[3]) = make_float4(g0.w, g1.w, g2.w, g3.w);            \
         bs.x += ((g0.x + g1.x) + g2.x) + g3.x;                                                      \
         bs.y += ((g0.y + g1.y) + g2.y) + g3.y;                                                      \
         bs.z += ((g0.z + g1.z) + g2.z) + g3.z;                                                      \
         bs.w += ((g0.w + g1.w) + g2.w) + g3.w;                                                      \
     }
     f32x4 aX0, aX1, aX2, aX3, bX0, bX1, bX2, bX3;
+    const int rd_slot = (lane >> 4) * 16 + (((lane & 15) + (lane >> 4)) & 15);   // this lane's (rotated) slot in a fragment block
 #define WB_READ(stage_, half_)                                                                      \
     {                                                                                               \
-        const float *As_r = wb_smem + (stage_) * 2 * WB_TILE + ((half_) * 8 + wave_m * 4) * 256 + lane * 4; \
-        const float *Bs_r = wb_smem + (stage_) * 2 * WB_TILE + WB_TILE + ((half_) * 8 + wave_n * 4) * 256 + lane * 4; \
+        const float *As_r = wb_smem + (stage_) * 2 * WB_TILE + ((half_) * 8 + wave_m * 4) * 256 + rd_slot * 4; \
+        const float *Bs_r = wb_smem + (stage_) * 2 * WB_TILE + WB_TILE + ((half_) * 8 + wave_n * 4) * 256 + rd_slot * 4; \
         aX0 = *reinterpret_cast<const f32x4 *>(As_r);                                               \
         bX0 = *reinterpret_cast<const f32x4 *>(Bs_r);                                               \
         aX1 = *reinterpret_cast<const f32x4 *>(As_r + 256);                                         \
@@ -635,6 +651,7 @@ void wgrad_big_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_ch
         __syncthreads();
     }
 #undef WB_LOAD_ROW
+#undef WB_FIX_ROW
 #undef WB_LOAD
 #undef WB_STORE
 #undef WB_READ

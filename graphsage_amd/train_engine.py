@@ -118,6 +118,11 @@ class SageTrainEngine(SageForwardEngine):
             return self._forward_walks_train(seeds, walk_ids, rng_seed, replay)
         self.sample(seeds, walk_ids, rng_seed, replay)
         for layer in range(self.n_hops):
+            if layer > 0 and self.wide_first_layer_only:
+                # wide models: the later layers have few rows; their neighbor means are needed in memory for
+                # the backward pass anyway, so they take gather-mean + the tiled projection
+                self._general_layer_train(layer)
+                continue
             for t in _TYPES:
                 call = self._train_call(layer, t)
                 if layer == 0 and seeds.data_ptr() != self.seeds_buf.data_ptr():
@@ -131,6 +136,22 @@ class SageTrainEngine(SageForwardEngine):
             else:
                 self.emb[t].copy_(self.z[t])
         return self.emb['user'], self.emb['item']
+
+    def _general_layer_train(self, layer):
+        m, other = self.model, self.other
+        last = layer == self.n_hops - 1
+        for t in _TYPES:
+            for (s, h, side, r0, n) in self.segments[t]:
+                if h > self.n_hops - 1 - layer:
+                    continue
+                _, c0, cn = self.where[s + 2]
+                kernels.gather_mean(self.h[layer - 1][other[t]][c0:c0 + cn], None, n, self.fanouts[h],
+                                    out=self.x_mean[layer][t][r0:r0 + n])
+        for t in _TYPES:
+            agg = m._aggs[layer][t]
+            rows = self.h[layer][t].shape[0]
+            kernels.sage_project(self.h[layer - 1][t][:rows], self.x_mean[layer][t][:rows], agg.w_self, agg.w_neigh,
+                                 agg.bias, agg.activation, out=self.z[t] if last else self.h[layer][t])
 
     def _g_self_dst(self, layer, t, g_prev):
         """Where the own-row input gradient of (layer, type) goes.  With one head
