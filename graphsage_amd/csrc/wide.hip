@@ -27,9 +27,9 @@
 //
 // All waves meet at one barrier per k slice.  Row ids of a tile (node id - table
 // offset, or "counts as zeros") are staged in LDS one tile ahead.  Neither the
-// gathered rows nor the means are written to memory by this kernel; when the
-// caller asks for copies (save_self / save_mean, for a backward pass) the gather
-// kernels make them beforehand.
+// gathered rows nor the means go through memory; when the caller asks for copies
+// (save_self / save_mean, for a backward pass) the producers also write each
+// finished piece there.
 #include "fused_args.h"
 
 namespace {
@@ -65,6 +65,8 @@ struct Cursor {
     int ct, side, ks;   // column tile, 0 own rows / 1 neighbor means, k slice
     int n_child;        // children per head in the tile's segment; looked up when the tile changes, so that
     float inv;          // a slice costs no scalar loads (their round trips were on every slice's critical path)
+    long long row0;     // output row of the tile's first head
+    int np;             // heads in the tile (128, fewer at the end of a segment)
 };
 
 struct Shape {
@@ -84,8 +86,12 @@ __device__ __forceinline__ int find_seg(const FusedArgs &a, int tile) {
 }
 
 __device__ __forceinline__ void enter_tile(Cursor &c, const FusedArgs &a) {
-    c.n_child = a.seg[find_seg(a, c.tile)].n_child;
+    const Seg &sg = a.seg[find_seg(a, c.tile)];
+    const long long p0 = (long long)(c.tile - (int)sg.tile0) * WM;
+    c.n_child = sg.n_child;
     c.inv = 1.0f / (float)c.n_child;
+    c.row0 = sg.out_row0 + p0;
+    c.np = (int)min((long long)WM, sg.n_heads - p0);
 }
 
 __device__ __forceinline__ void advance(Cursor &c, const Shape &sh, const FusedArgs &a) {
@@ -126,6 +132,7 @@ struct Producer {
         int cnt;                                     // children in the chunk in flight
         bool bad;                                    // some lane of this wave has such a load
         float inv;
+        uint32_t save_lo[PP], save_hi[PP];           // address (two halves) where a copy of the finished piece goes, or 0
     };
     // ids in flight
     int32_t cv[IDC], hv;
@@ -236,6 +243,16 @@ struct Producer {
         }
         load_chunk<true>(s, base, fb, rows, n, (nch - 1) * CH, n - (nch - 1) * CH);
         s.inv = c.side ? c.inv : 1.0f;
+        // copies for a backward pass: the own rows / the neighbor means, written once (first column tile)
+        float *sv = c.side ? a.save_mean : a.save_self;
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            const int row = p * RSTEP + a_r0;
+            const unsigned long long addr = (sv && c.ct == 0 && row < c.np)
+                ? reinterpret_cast<unsigned long long>(sv + (c.row0 + row) * F + c.ks * WK + a_kq * 4) : 0ull;
+            s.save_lo[p] = (uint32_t)addr;
+            s.save_hi[p] = (uint32_t)(addr >> 32);
+        }
     }
 
     // the slice in flight: last chunk added, mean taken, both operand slices written to LDS stage `buf`
@@ -247,6 +264,8 @@ struct Producer {
         for (int p = 0; p < PP; ++p) {
             s.acc[p] *= s.inv;
             *reinterpret_cast<f32x4 *>(As + a_dst[p]) = s.acc[p];
+            const unsigned long long addr = ((unsigned long long)s.save_hi[p] << 32) | s.save_lo[p];
+            if (addr) *reinterpret_cast<f32x4 *>(addr) = s.acc[p];
         }
     }
 
@@ -319,7 +338,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     if (tid >= kConsumerThreads) {
         Producer<NPT, CH, BIG> pr(a, sh, st, hrow, crow, tid - kConsumerThreads, tid - kConsumerThreads);
         typename Producer<NPT, CH, BIG>::Slice s0, s1;             // slices of even / odd index
-        Cursor cl{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f};      // next slice to load
+        Cursor cl{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0};      // next slice to load
         enter_tile(cl, a);
         Cursor cc = cl;                                            // slice the consumers multiply
         int gl = 0;                                                // index of cl; past the last slice it stays there
@@ -456,7 +475,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         *reinterpret_cast<float4 *>(Bw + WD_B_DST(3)) = bw3;                                           \
     }
 
-    Cursor c{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f}, done = c;
+    Cursor c{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0}, done = c;
     bool pending = false;
     block_sync();
     WD_LOAD_B(c);
@@ -532,30 +551,6 @@ int gs::sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream) {
     a.n_tiles = tiles;
     if (tiles == 0) return GS_OK;
     if (tiles >= (1ll << 24)) return gs::fail(GS_ELIMIT, "gs_sage_fused_fwd: more than 2^31 head nodes in one call");
-    // Copies of the own rows / neighbor means for a backward pass: made by the gather kernels before
-    // the layer runs (the fused kernel itself writes nothing but the layer's output).
-    for (int s = 0; s < a.n_segs && (a.save_self || a.save_mean); ++s) {
-        const Seg &g = a.seg[s];
-        if (g.n_heads == 0) continue;
-        int rc = GS_OK;
-        if (a.save_self) {
-            float *dst = a.save_self + g.out_row0 * Fs;
-            if (g.head_ids) rc = gs_gather_rows(a.feat_self, a.n_rows_self, Fs, a.off_self, g.head_ids, g.n_heads, dst, stream);
-            else if (hipMemcpyAsync(dst, a.feat_self + g.self_row0 * Fs, (size_t)g.n_heads * Fs * sizeof(float),
-                                    hipMemcpyDeviceToDevice, stream) != hipSuccess)
-                rc = gs::fail(GS_ELAUNCH, "gs_sage_fused_fwd: copy of the own rows failed");
-        }
-        if (rc == GS_OK && a.save_mean) {
-            float *dst = a.save_mean + g.out_row0 * Fn;
-            if (g.child_ids) rc = gs_gather_mean_fwd(a.feat_neigh, a.n_rows_neigh, Fn, a.off_neigh, g.child_ids, g.n_heads, g.n_child, dst, stream);
-            else rc = gs_gather_mean_fwd(a.feat_neigh + g.child_row0 * Fn, a.n_rows_neigh - g.child_row0, Fn, 0, nullptr, g.n_heads, g.n_child, dst, stream);
-        }
-        if (rc != GS_OK) return rc;
-    }
-    if (a.n_rows_self >= (1ll << 31) || a.n_rows_neigh >= (1ll << 31))
-        return gs::fail(GS_ELIMIT, "gs_sage_fused_fwd: the wide kernel indexes table rows with 32 bits");
-    if ((reinterpret_cast<uintptr_t>(a.out) & 15) != 0)
-        return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: out must be 16-byte aligned");
     // tables below 4 GB are addressed with 32-bit byte offsets
     const bool big = (unsigned long long)a.n_rows_self * Fs * 4ull >= (1ull << 32) - 1024 ||
                      (unsigned long long)a.n_rows_neigh * Fn * 4ull >= (1ull << 32) - 1024;

@@ -244,8 +244,7 @@ int gs_l2_normalize_bwd(const float *x, const float *g_out, int64_t M, int H,
  * H/2 of 16 or 32) keep all weights in LDS and give a wavefront 16 heads at a
  * time; wide layers (widths multiples of 32 and at least 64, H/2 a multiple of
  * 128, n_child <= 32) are tiled 128 heads x 128 columns with the gathers on
- * their own wavefronts beside the matrix product.  For wide layers the save_*
- * copies are made by the gather kernels before the layer runs, and normalize
+ * their own wavefronts beside the matrix product.  For wide layers normalize
  * runs as a second small kernel on out.
  */
 typedef struct gs_fused_segment {
