@@ -201,10 +201,11 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
 #define GS_SEL(f) (second ? s1.f : s0.f)
     const int col0 = ((int)blockIdx.y - (second ? ncb0 : 0)) * GB_N;
     const float *__restrict__ A = GS_SEL(A);
+    const float *__restrict__ Am = GS_SEL(mask);           // element of A counts only where the mask is > 0 (or NULL)
     const float *__restrict__ B = GS_SEL(B);
     const float *__restrict__ bias = GS_SEL(bias);
     float *__restrict__ outp = GS_SEL(out);
-    const int K = GS_SEL(K), lda = GS_SEL(lda), ldbk = GS_SEL(ldbk), ldo = GS_SEL(ldo);
+    const int K = GS_SEL(K), lda = GS_SEL(lda), ldbk = GS_SEL(ldbk), ldbn = GS_SEL(ldbn), ldo = GS_SEL(ldo);
     const int32_t *__restrict__ row_ids = GS_SEL(row_ids);
     const long long id_off = GS_SEL(id_off), n_table = GS_SEL(n_table);
 #undef GS_SEL
@@ -216,6 +217,7 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     // staging roles.  A: GB_KQ lanes cover one row's slice (16 bytes each), 256/GB_KQ rows per pass.
     const int a_kq = tid % GB_KQ;
     const float *a_src[GB_NP];
+    const float *a_msk[GB_NP];                          // the same elements of the mask
     bool a_zero[GB_NP];
     int a_dst[GB_NP];
 #pragma unroll
@@ -226,6 +228,7 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
         const int64_t srow = gemm_src_row(row_ids, id_off, n_table, grow);
         a_zero[p] = srow < 0;                           // an id outside the table: the row counts as zeros
         a_src[p] = A + (srow < 0 ? 0 : srow) * lda + a_kq * 4;
+        a_msk[p] = Am ? Am + (srow < 0 ? 0 : srow) * lda + a_kq * 4 : nullptr;
         // within a fragment block the 16 slots of a lane quarter are rotated by GB_NR * (k quad): the
         // 16-lane groups of this write (GB_NR rows x GB_KQ k quads) and of the fragment read (sixteen
         // rows of one quad) then both touch sixteen different 16-byte bank groups
@@ -239,7 +242,7 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
     for (int j = 0; j < GB_NP; ++j) {
         const int idx = j * 256 + tid;
         const int col = idx & 127, kquad = idx >> 7;
-        b_src[j] = B + (int64_t)(kquad * 4) * ldbk + col0 + col;
+        b_src[j] = B + (int64_t)(kquad * 4) * ldbk + (int64_t)(col0 + col) * ldbn;
         b_dst[j] = ((kquad >> 2) * 8 + (col >> 4)) * 256 + ((kquad & 3) * 16 + (col & 15)) * 4;
     }
 
@@ -254,6 +257,7 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
 
     // the slice in flight lives in named registers (an indexed array here ends up in scratch)
     float4 ar0, ar1, ar2 = make_float4(0.f, 0.f, 0.f, 0.f), ar3 = ar2, br0, br1, br2 = ar2, br3 = ar2;
+    float4 am0 = make_float4(1.f, 1.f, 1.f, 1.f), am1 = am0, am2 = am0, am3 = am0;   // mask values of the slice in flight
 #define GB_LOAD_B(dst_, j_, k0_)                                                                   \
     {                                                                                              \
         const float *src = b_src[j_] + (int64_t)(k0_) * ldbk;                                      \
@@ -268,6 +272,14 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
             ar2 = *reinterpret_cast<const float4 *>(a_src[GB_NP - 2] + k0);                        \
             ar3 = *reinterpret_cast<const float4 *>(a_src[GB_NP - 1] + k0);                        \
         }                                                                                          \
+        if (Am) {                                            /* applied when the slice is stored */ \
+            am0 = *reinterpret_cast<const float4 *>(a_msk[0] + k0);                    \
+            am1 = *reinterpret_cast<const float4 *>(a_msk[1] + k0);                    \
+            if constexpr (GB_NP == 4) {                                                            \
+                am2 = *reinterpret_cast<const float4 *>(a_msk[GB_NP - 2] + k0); \
+                am3 = *reinterpret_cast<const float4 *>(a_msk[GB_NP - 1] + k0); \
+            }                                                                                      \
+        }                                                                                          \
         if (row_ids) {                                                                             \
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);                                     \
             if (a_zero[0]) ar0 = z4;                                                               \
@@ -277,8 +289,17 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
         GB_LOAD_B(br0, 0, k0) GB_LOAD_B(br1, 1, k0)                                                \
         if constexpr (GB_NP == 4) { GB_LOAD_B(br2, GB_NP - 2, k0) GB_LOAD_B(br3, GB_NP - 1, k0) }  \
     }
+#define GB_MASK(a_, m_)                                                                            \
+    if (!(m_.x > 0.f)) a_.x = 0.f;                                                                 \
+    if (!(m_.y > 0.f)) a_.y = 0.f;                                                                 \
+    if (!(m_.z > 0.f)) a_.z = 0.f;                                                                 \
+    if (!(m_.w > 0.f)) a_.w = 0.f;
 #define GB_STORE_SLICE(stage_)                                                                     \
     {                                                                                              \
+        if (Am) {                                                                                  \
+            GB_MASK(ar0, am0) GB_MASK(ar1, am1)                                                    \
+            if constexpr (GB_NP == 4) { GB_MASK(ar2, am2) GB_MASK(ar3, am3) }                      \
+        }                                                                                          \
         float *As_w = gb_smem + (stage_) * 2 * GB_TILE, *Bs_w = As_w + GB_TILE;                    \
         *reinterpret_cast<float4 *>(As_w + a_dst[0]) = ar0;                                        \
         *reinterpret_cast<float4 *>(As_w + a_dst[1]) = ar1;                                        \
@@ -345,6 +366,7 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
 #undef GB_LOAD_SLICE
 #undef GB_LOAD_B
 #undef GB_STORE_SLICE
+#undef GB_MASK
 
     // Epilogue through LDS, 64 rows at a time: accumulators (+ bias, activation) are laid out as
     // rows of the output tile, then every thread writes 16-byte pieces of whole rows (a row of the
@@ -383,8 +405,9 @@ void rows_gemm_big_kernel(GemmSide s0, GemmSide s1, int64_t M, int act) {
 }
 
 inline bool big_gemm_applies(const GemmSide &s) {
-    return s.vec && s.K % GB_K == 0 && s.N % GB_N == 0 && s.ldbn == 1 && !s.mask &&
+    return s.vec && s.K % GB_K == 0 && s.N % GB_N == 0 && !(s.mask && s.row_ids) &&
            (reinterpret_cast<uintptr_t>(s.A) & 15) == 0 && s.lda % 4 == 0 &&
+           (!s.mask || (reinterpret_cast<uintptr_t>(s.mask) & 15) == 0) &&
            (reinterpret_cast<uintptr_t>(s.out) & 15) == 0 && s.ldo % 4 == 0;
 }
 
@@ -1072,7 +1095,19 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
         const int64_t bx = (M + BM - 1) / BM;
         const int by = s0.ncb + s1.ncb;
         if (bx > 0x7FFFFFFFLL || by > 65535) return gs::fail(GS_ELIMIT, "gs_sage_project_bwd: grid %lld x %d too large", (long long)bx, by);
-        hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)bx, (unsigned)by), dim3(kThreads), 0, s, s0, s1, M, GS_ACT_LINEAR);
+        // wide layers: both input gradients on the 128x128-tile kernel (a side that is not wanted has N = 0)
+        const bool big0 = s0.N == 0 || big_gemm_applies(s0), big1 = s1.N == 0 || big_gemm_applies(s1);
+        if (big0 && big1 && M >= 4 * GB_M) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rows_gemm_big_kernel),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS);
+            if (attr != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage_project_bwd: %s", hipGetErrorString(attr));
+            const int64_t gx = (M + GB_M - 1) / GB_M;
+            const int gy = s0.N / GB_N + s1.N / GB_N;
+            hipLaunchKernelGGL(rows_gemm_big_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), GB_LDS, s, s0, s1, M,
+                               GS_ACT_LINEAR);
+        } else {
+            hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)bx, (unsigned)by), dim3(kThreads), 0, s, s0, s1, M, GS_ACT_LINEAR);
+        }
         if (int rc = gs::check_launch("gs_sage_project_bwd (dx)")) return rc;
     }
     return GS_OK;
