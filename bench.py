@@ -9,6 +9,11 @@ per-type MFMA projections -> second layer -> l2-normalised user/item embeddings.
 N > 1 (launched by torch.distributed.run): the graph and features are replicated,
 rank r takes its own batches of seed edges, the forward pass needs no collective,
 and the reported value is the sum over ranks divided by the slowest rank's time.
+
+Environment switches for comparisons: BENCH_UNFUSED=1 runs the forward pass on the
+general kernels (sample, gather-mean, projection) instead of the fused ones;
+BENCH_EAGER_TRAIN=1 launches the training step kernel by kernel instead of
+replaying a captured HIP graph; BENCH_WATCHDOG_S bounds the whole run.
 """
 import argparse
 import json
