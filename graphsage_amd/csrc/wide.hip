@@ -213,6 +213,18 @@ struct Producer {
 #pragma unroll
                 for (int u = 0; u < CH; ++u) s.v[p][u] = (s.mask >> (p * CH + u)) & 1u ? z4 : s.v[p][u];
         }
+        if (s.cnt == 1) {                                          // own rows
+#pragma unroll
+            for (int p = 0; p < PP; ++p) s.acc[p] += s.v[p][0];
+            return;
+        }
+        if (s.cnt == CH) {                                         // the common case without per-child selects
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int p = 0; p < PP; ++p) s.acc[p] += s.v[p][u];
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             if (u < s.cnt) {                                       // uniform
