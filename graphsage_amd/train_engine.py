@@ -23,6 +23,9 @@ class SageTrainEngine(SageForwardEngine):
         # Feature widths that are not multiples of 32 (MovieLens: 28 / 18 columns) run through zero-padded
         # copies of the tables and of the layer-0 weights; the real weights and their gradients are copied
         # in and out around every pass (padding.py).
+        if getattr(model, 'dropout', 0.0):
+            raise kernels._lib.GsageError("the training plan has no dropout; a model with dropout > 0 trains through "
+                                          "graphsage_amd.train.Trainer(engine='autograd')")
         self._padded_model = None
         f = graph.node_feature_sizes
         if any(f[t] % 32 for t in _TYPES):

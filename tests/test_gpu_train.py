@@ -311,3 +311,15 @@ def test_staged_epoch_rows_equal_the_per_batch_roots(cuda):
     bad = gen.flow(links[:31] + [(links[0][0], 10 ** 6)], targets=np.zeros(32), shuffle=False)
     with pytest.raises(KeyError):                                # unknown node in a later link, as roots() raises
         bad.epoch_on_device()
+
+
+def test_dropout_models_train_through_autograd(cuda):
+    """The static plan implements no dropout (models.py:113-115 applies it to every layer input while
+    training): 'auto' must not pick it, 'plan' must refuse."""
+    g, links, targets = _toy(1, fu=32, fi=32)
+    gen = ga.GraphSAGEGenerator(g, 16, [3, 2], head_node_types=['user', 'item'], seed=1)
+    model = ga.GraphSAGE([32, 32], gen, dropout=0.5, seed=2)
+    assert Trainer(model, lr=1e-2, graph=g, batch_size=16).engine is None
+    with pytest.raises(Exception):
+        Trainer(model, lr=1e-2, engine='plan', graph=g, batch_size=16)
+    assert Trainer(ga.GraphSAGE([32, 32], gen, seed=2), lr=1e-2, graph=g, batch_size=16).engine is not None
