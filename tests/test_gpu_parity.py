@@ -824,3 +824,34 @@ def test_launch_timer_brackets_exactly_one_kernel(cuda):
     kernels.gather_rows(feat, ids[:1000].contiguous())        # not one of the timed kernels: stays armed
     kernels.gather_mean(feat, ids, 50_000, 10)
     assert t2.elapsed_us() > 1.0
+
+
+@pytest.mark.parametrize('ns,sizes,f', [([8, 4], [32, 32], 64), ([4, 3, 2], [32, 64, 32], 32)])
+def test_engines_without_bias_and_without_normalisation(cuda, ns, sizes, f):
+    """GraphSAGE(bias=False, normalize=None) (models.py:19-35): every forward route agrees with the oracle."""
+    from graphsage_amd.engine import SageForwardEngine
+    rng = np.random.default_rng(8)
+    nu, ni, b = 200, 50, 24
+    u = np.concatenate([rng.integers(0, nu, 1500), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 1500), np.arange(nu) % ni]) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, f)).astype(np.float32),
+             'item': rng.standard_normal((ni, f)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=21)
+    model = ga.GraphSAGE(sizes, gen, bias=False, normalize=None, seed=5).build()
+    assert all(a.bias is None for aggs in model._aggs for a in aggs.values())
+    links = [(int(e[0, i]), int(e[1, i])) for i in range(b)]
+    seeds = torch.tensor([l[0] for l in links] + [l[1] for l in links], dtype=torch.int32, device=cuda)
+    walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda)
+    engines = [SageForwardEngine(g, model, b), SageForwardEngine(g, model, b, walk_kernel=False),
+               SageForwardEngine(g, model, b, use_fused=False)]
+    outs = [[x.clone() for x in eng.forward(seeds, walk_ids, rng_seed=5)] for eng in engines]
+    want_hops = walker.walk_vectorised(g.indptr, g.indices, seeds.cpu().numpy(), ns, rng_seed=5, first_walk=0)
+    xin = ogen.sample_features_fast({k: v.astype(np.float64) for k, v in feats.items()}, nu, links, want_hops)
+    plan = omodel.LayerPlan(sizes, ns, g.node_feature_sizes)
+    want = omodel.forward(plan, _oracle_model(model, plan), [torch.from_numpy(x) for x in xin], normalize=None)
+    for out in outs:
+        for k in range(2):
+            close(out[k], want[k], scale=float(want[k].abs().max()))

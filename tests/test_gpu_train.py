@@ -323,3 +323,32 @@ def test_dropout_models_train_through_autograd(cuda):
     with pytest.raises(Exception):
         Trainer(model, lr=1e-2, engine='plan', graph=g, batch_size=16)
     assert Trainer(ga.GraphSAGE([32, 32], gen, seed=2), lr=1e-2, graph=g, batch_size=16).engine is not None
+
+
+def test_plan_step_without_bias_and_normalisation_equals_autograd(cuda):
+    g, links, targets = _toy(4, fu=64, fi=64)
+    b, ns = 32, [6, 3]
+    results = []
+    for engine in ('autograd', 'plan'):
+        gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+        model = ga.GraphSAGE([32, 32], gen, bias=False, normalize=None, seed=11).build()
+        from graphsage_amd.train import LinkHead
+        tr = Trainer(model, head=LinkHead(32, cuda, seed=5), lr=1e-2, engine=engine, graph=g, batch_size=b)
+        lk = np.asarray(links[:b])
+        seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+        walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda)
+        t = torch.from_numpy(targets[:b]).to(cuda)
+        if engine == 'plan':
+            assert tr.engine is not None
+            loss, _ = tr.step_device(seeds, t, walk_ids, rng_seed=9)
+        else:
+            hops, _ = ga.kernels.sample(g.device_tensors()['indptr'], g.device_tensors()['indices'], seeds, ns,
+                                        rng_seed=9, walk_ids=walk_ids)
+            slot_ids = [seeds[:b].reshape(b, 1), seeds[b:].reshape(b, 1)]
+            for hop in hops:
+                slot_ids += [hop[:b], hop[b:]]
+            loss, _ = tr.step(ga.BatchFeatures(g, b, slot_ids, gen._slot_types), targets[:b])
+        results.append((float(loss), tr.bucket.flat.clone()))
+    (l0, g0), (l1, g1) = results
+    assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0))
+    assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
