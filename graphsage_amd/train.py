@@ -153,6 +153,11 @@ class Trainer:
         self._graph_obj, self._batch_size = graph, batch_size
         self.group = group
         self.engine = None
+        if not isinstance(self.head, LinkHead):
+            # heads other than concat -> Dense(1, sigmoid) are torch modules: the model trains through autograd
+            if engine == 'plan':
+                raise ValueError("engine='plan' needs the concat -> Dense(1, sigmoid) head (train.LinkHead)")
+            engine = 'autograd'
         if engine in ('auto', 'plan') and graph is not None and batch_size is not None:
             from .train_engine import SageTrainEngine
             try:

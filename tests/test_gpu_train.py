@@ -266,7 +266,16 @@ def test_movielens_format_fit_learns_and_both_step_paths_agree(cuda, tmp_path):
     ev = t_plan.evaluate(test)
     assert abs(ev['auc'] - h_plan['val_auc'][-1]) < 1e-9
     with pytest.raises(NotImplementedError):
-        link_classification(edge_embedding_method='ip')
+        link_classification(edge_embedding_method='no-such-operator')
+    # another operator of link_utils.py: a torch head, trained through autograd
+    gen = ga.GraphSAGEGenerator(g, 100, [8, 4], head_node_types=['user', 'item'], seed=3)
+    train = gen.flow([links[i] for i in tr_idx[:2000]], targets=data['labels'][tr_idx[:2000]], shuffle=True, seed=4)
+    model = ga.GraphSAGE([32, 32], gen, seed=7)
+    head = link_classification(edge_embedding_method='mul')(model.in_out_tensors()[1], seed=8)
+    t_mul = Trainer(model, head=head, lr=1e-2, graph=g, batch_size=100)
+    assert t_mul.engine is None
+    h_mul = t_mul.fit(train, epochs=3, verbose=0)
+    assert h_mul['loss'][-1] < h_mul['loss'][0]
 
 
 def test_fit_surfaces_a_node_without_neighbors_like_the_reference(cuda):
