@@ -186,3 +186,39 @@ def test_walk_kernel_reads_feature_tables_beyond_4_gib_with_plain_loads(cuda):
         assert (out_w[k] - out_u[k]).abs().max().item() <= 1e-5
     del g, u, it, eng_w, eng_u
     torch.cuda.empty_cache()
+
+
+def test_wide_layer_kernel_reads_a_table_beyond_4_gib(cuda):
+    """A 4.5 GB neighbor table: the wide fused layer keeps row indices (not 32-bit byte offsets) in LDS and
+    forms 64-bit addresses.  Checked against gather-mean + projection on the same ids, and a few rows against
+    float64 arithmetic on the host."""
+    rows, fn, fs, h = 1_100_000, 1024, 64, 256
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    t_neigh = torch.randn((rows, fn), device=cuda, generator=gen)
+    assert t_neigh.numel() * 4 > 1 << 32
+    t_self = torch.randn((5000, fs), device=cuda, generator=gen)
+    ws = torch.randn((fs, h // 2), device=cuda, generator=gen) * 0.1
+    wn = torch.randn((fn, h // 2), device=cuda, generator=gen) * 0.03
+    bias = torch.randn(h, device=cuda, generator=gen) * 0.1
+    segs, want = [], []
+    for n_heads, nc in [(3000, 5), (300, 12)]:
+        heads = torch.randint(0, t_self.shape[0], (n_heads,), device=cuda, generator=gen, dtype=torch.int32)
+        kids = torch.randint(0, rows, (n_heads * nc,), device=cuda, generator=gen, dtype=torch.int32)
+        kids[-nc:] = rows - 1                                  # the last row of the table: highest address
+        kids[::53] = -1
+        segs.append({'head_ids': heads, 'child_ids': kids, 'n_heads': n_heads, 'n_child': nc})
+        xs = kernels.gather_rows(t_self, heads, 0)
+        xm = kernels.gather_mean(t_neigh, kids, n_heads, nc, 0)
+        want.append(kernels.sage_project(xs, xm, ws, wn, bias, 'relu'))
+    want = torch.cat(want)
+    assert kernels.fused_supported(fs, fn, h, 12)
+    got = kernels.sage_fused(t_self, 0, t_neigh, 0, segs, ws, wn, bias, 'relu')
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * scale
+    # last head of the second segment on the host in float64
+    kid = segs[1]['child_ids'][-12:].cpu().numpy()
+    xn = np.stack([t_neigh[k].cpu().numpy().astype(np.float64) if k >= 0 else np.zeros(fn) for k in kid]).mean(0)
+    xs = t_self[int(segs[1]['head_ids'][-1])].cpu().numpy().astype(np.float64)
+    row = np.concatenate([xs @ ws.cpu().numpy().astype(np.float64), xn @ wn.cpu().numpy().astype(np.float64)])
+    row = np.maximum(row + bias.cpu().numpy(), 0.0)
+    assert np.abs(got[-1].cpu().numpy() - row).max() <= 2e-5 * max(1.0, np.abs(row).max())
