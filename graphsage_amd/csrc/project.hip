@@ -871,10 +871,11 @@ void wgrad_direct_kernel(const float *__restrict__ Xs, const float *__restrict__
     X(32, 32, 1) X(32, 64, 1) X(64, 32, 1) X(64, 64, 1) X(64, 128, 1) X(128, 64, 1) X(128, 128, 1) X(32, 128, 1) X(128, 32, 1) \
     X(32, 32, 2) X(32, 64, 2) X(64, 32, 2) X(64, 64, 2) X(64, 128, 2) X(128, 64, 2) X(128, 128, 2) X(32, 128, 2) X(128, 32, 2)
 
-// rows per block for the direct kernel: at most 512 blocks, at least 128 rows each (so the
-// slab count never exceeds the chunk count the workspace was sized for)
+// rows per block for the direct kernel: at most 256 blocks (one per CU: fewer slabs for the
+// reduction that follows), at least 128 rows each (so the slab count never exceeds the chunk
+// count the workspace was sized for)
 inline int64_t wgrad_direct_rows(int64_t M) {
-    int64_t rpb = (M + 511) / 512;
+    int64_t rpb = (M + 255) / 256;
     rpb = ((rpb + 15) / 16) * 16;
     return rpb < 128 ? 128 : rpb;
 }
