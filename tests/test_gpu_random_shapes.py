@@ -168,3 +168,63 @@ def test_forward_engine_random_models_against_the_oracle(cuda, seed):
     want = omodel.forward(plan, weights, [torch.from_numpy(x) for x in xin], agg=agg)
     for k in range(2):
         assert (out[k].cpu().double() - want[k]).abs().max().item() <= 1e-5, (n_hops, fan, fu, fi, sizes, agg)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_fused_layer_random_shapes_equal_the_general_kernels(cuda, seed):
+    """One aggregator layer through the fused kernels (narrow and 128-multiple wide) on random
+    widths, segment lists, fan-outs, invalid ids and options, against gather + gather-mean +
+    projection (+ l2norm) on the same inputs."""
+    rng = np.random.default_rng(400 + seed)
+    wide = seed % 2 == 1
+    if wide:
+        fs, fn = int(rng.choice([64, 96, 128, 256])), int(rng.choice([64, 160, 256]))
+        h = int(rng.choice([256, 512]))
+        max_child = 32
+    else:
+        fs, fn, h = [(64, 64, 32), (32, 32, 32), (64, 64, 64), (128, 64, 32), (32, 128, 64)][int(rng.integers(0, 5))]
+        max_child = 64
+    assert kernels.fused_supported(fs, fn, h, 1), (fs, fn, h)
+    n_self, n_neigh = int(rng.integers(1, 4000)), int(rng.integers(1, 4000))
+    off_s, off_n = int(rng.integers(0, 50)), int(rng.integers(0, 5000))
+    gen = torch.Generator(device=cuda).manual_seed(seed)
+    t_self = torch.randn((n_self, fs), device=cuda, generator=gen)
+    t_neigh = torch.randn((n_neigh, fn), device=cuda, generator=gen)
+    ws = torch.randn((fs, h // 2), device=cuda, generator=gen) * 0.1
+    wn = torch.randn((fn, h // 2), device=cuda, generator=gen) * 0.1
+    bias = torch.randn(h, device=cuda, generator=gen) * 0.1 if rng.integers(0, 4) else None
+    act = str(rng.choice(['relu', 'linear']))
+    normalize = bool(rng.integers(0, 2))
+    segs, want, want_s, want_m = [], [], [], []
+    biggest = 1
+    for _ in range(int(rng.integers(1, 5))):
+        n_heads = int(rng.choice([1, 2, 127, 128, 129, int(rng.integers(1, 700))]))
+        nc = int(rng.integers(1, max_child + 1))
+        while nc > 1 and not kernels.fused_supported(fs, fn, h, max(biggest, nc)):   # narrow layers: LDS bounds the fan-out
+            nc //= 2
+        biggest = max(biggest, nc)
+        heads = rng.integers(0, n_self, n_heads).astype(np.int32) + off_s
+        kids = rng.integers(0, n_neigh, n_heads * nc).astype(np.int32) + off_n
+        kids[rng.random(kids.size) < 0.05] = -1                              # below an isolated node
+        kids[rng.random(kids.size) < 0.02] = off_n + n_neigh                 # just past the table
+        heads[rng.random(heads.size) < 0.03] = off_s - 1 if off_s else -1    # just before it
+        heads, kids = torch.from_numpy(heads).to(cuda), torch.from_numpy(kids).to(cuda)
+        segs.append({'head_ids': heads, 'child_ids': kids, 'n_heads': n_heads, 'n_child': nc})
+        xs = kernels.gather_rows(t_self, heads, off_s)
+        xm = kernels.gather_mean(t_neigh, kids, n_heads, nc, off_n)
+        o = kernels.sage_project(xs, xm, ws, wn, bias, act)
+        want.append(kernels.l2_normalize(o) if normalize else o)
+        want_s.append(xs)
+        want_m.append(xm)
+    assert kernels.fused_supported(fs, fn, h, biggest), (fs, fn, h, biggest)
+    want = torch.cat(want)
+    save = bool(rng.integers(0, 2))
+    save_s = torch.empty((want.shape[0], fs), device=cuda) if save else None
+    save_m = torch.empty((want.shape[0], fn), device=cuda) if save else None
+    got = kernels.sage_fused(t_self, off_s, t_neigh, off_n, segs, ws, wn, bias, act, normalize=normalize,
+                             save_self=save_s, save_mean=save_m)
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= 2e-5 * scale, (fs, fn, h, act, normalize)
+    if save:
+        assert torch.equal(save_s, torch.cat(want_s))
+        assert float((save_m - torch.cat(want_m)).abs().max()) <= 1e-5 * max(1.0, float(torch.cat(want_m).abs().max()))
