@@ -1,7 +1,6 @@
 """Times one wide fused layer (gs_sage_fused_fwd on 256-wide inputs) on synthetic ids.
 python tools/time_wide.py [heads] [n_child] [table_rows]"""
 import sys
-import time
 
 import torch
 
