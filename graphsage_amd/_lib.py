@@ -76,6 +76,8 @@ SIGNATURES['gs_sage2_forward'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _
                                          _c.POINTER(SageWeights), _c.POINTER(SageWeights),
                                          _c.POINTER(SageWeights), _c.POINTER(SageWeights),
                                          _i32, _i32, _i32, _vp, _vp, _vp, _c.POINTER(Sage2Saved), _vp, _vp])
+SIGNATURES['gs_sage2_backward_tail'] = (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
+                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 
 _f32 = _c.c_float
 SIGNATURES['gs_link_head_workspace'] = (_sz, [_i64, _i32])

@@ -1,0 +1,124 @@
+// Backward of the top of the two-hop model, one wavefront per root: from the gradients of the
+// embeddings down to the gradients of the layer-0 activations, in one launch.
+//
+//   g_z[t][p]                = l2-normalisation backward of g_emb[t][p] at z[t][p]   (models.py:32)
+//   g_h1[t][p]               = (g_z[t][p][:H2/2] . W1_self[t]^T)                      (utils.py:109-119, the root's own input)
+//   g_h1[o][B + p*n0 + j]    = (g_z[t][p][H2/2:] . W1_neigh[t]^T) / n0,  j < n0       (utils.py:103-109: the mean over its n0
+//                                                                                      hop-1 heads, which are of the other type o)
+//
+// with the row layout gs_sage2_forward uses for its saved tables (row p: root of pair p of that type;
+// row B + p*n0 + j: hop-1 head j of the walk rooted at the other type's root of pair p), so the two
+// g_h1 tables are written completely: every row exactly once.  This replaces gs_l2_normalize_bwd, the
+// input-gradient half of gs_sage_project_bwd and gs_gather_mean_bwd of the layer-by-layer route -- three
+// dependent launches per node type of a few microseconds each -- by one.  The layer-1 weight gradients
+// are still taken from g_z by gs_sage_project_bwd.
+//
+// A row is at most 64 wide, so lane c owns column c: the two 32- or 64-long dot products per lane read
+// the weights from LDS, staged once per block transposed ([n][k], lanes along k: conflict-free), and
+// g_z from a per-wave LDS line (broadcast reads).
+#include "gs_common.h"
+
+namespace {
+
+constexpr int kThreads = 1024;             // sixteen waves share one staged copy of the weights
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxH = 64;
+
+struct TailArgs {
+    const float *z[2], *g_emb[2], *w_self[2], *w_neigh[2];
+    float *g_z[2], *g_h1[2];
+    long long n_pairs;
+    int n0, H1, H2, normalize, relu;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ __launch_bounds__(kThreads)
+void sage2_tail_bwd_kernel(const TailArgs a) {
+    extern __shared__ float smem[];
+    const int H1 = a.H1, H2 = a.H2, HH2 = H2 / 2;
+    const int wsz = HH2 * H1;
+    float *wt = smem;                                             // [type][self, neigh][n][k]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *gz_s = smem + 4 * wsz + wave * kMaxH;                  // this wave's g_z row
+    for (int i = threadIdx.x; i < 4 * wsz; i += kThreads) {
+        const int m = i / wsz, e = i - m * wsz;                   // e = k * HH2 + n: the weights are read in memory order
+        const int k = e / HH2, n = e - k * HH2;
+        const float *W = (m & 1) ? a.w_neigh[m >> 1] : a.w_self[m >> 1];
+        wt[m * wsz + n * H1 + k] = W[e];
+    }
+    __syncthreads();
+
+    const int k = lane & (H1 - 1);                                // H1 is 32 or 64: lanes 32..63 repeat 0..31 when it is 32
+    const float inv_n0 = 1.f / (float)a.n0;
+    const long long walks = 2 * a.n_pairs;
+    for (long long w = (long long)blockIdx.x * kWaves + wave; w < walks; w += (long long)gridDim.x * kWaves) {
+        const int t = w >= a.n_pairs, o = 1 - t;
+        const long long p = w - (t ? a.n_pairs : 0);
+        float zc = 0.f, gc = 0.f;
+        if (lane < H2) { zc = a.z[t][p * H2 + lane]; gc = a.g_emb[t][p * H2 + lane]; }
+        float gz = gc;
+        if (a.normalize) {
+            const float ss = wave_sum(zc * zc), dot = wave_sum(zc * gc);
+            const float s = rsqrtf(fmaxf(ss, 1e-12f));
+            const float c3 = ss > 1e-12f ? s * s * s * dot : 0.f;
+            gz = s * gc - c3 * zc;
+        }
+        if (lane < H2) a.g_z[t][p * H2 + lane] = gz;
+        gz_s[lane] = (a.relu && !(zc > 0.f)) ? 0.f : gz;          // through the layer's own activation
+        wave_lds_fence();
+        const float *ws = wt + (2 * t) * wsz, *wn = ws + wsz;
+        float ds = 0.f, dn = 0.f;
+        for (int n = 0; n < HH2; ++n) {
+            ds = fmaf(gz_s[n], ws[n * H1 + k], ds);
+            dn = fmaf(gz_s[HH2 + n], wn[n * H1 + k], dn);
+        }
+        if (lane < H1) a.g_h1[t][p * H1 + lane] = ds;
+        // the n0 hop-1 heads of this walk: n0 * H1 consecutive floats, column = index mod H1 = this lane's k
+        const float v = dn * inv_n0;
+        float *dst = a.g_h1[o] + (a.n_pairs + p * a.n0) * H1;
+        const int span = a.n0 * H1;
+        for (int i = lane; i < span; i += 64) dst[i] = v;
+        wave_lds_fence();                                         // gz_s is rewritten by the next walk
+    }
+}
+
+}  // namespace
+
+extern "C" int gs_sage2_backward_tail(const float *z_user, const float *z_item,
+                                      const float *g_emb_user, const float *g_emb_item,
+                                      int64_t n_pairs, int n0, int H1, int H2, int normalize, int act,
+                                      const float *w1_self_user, const float *w1_neigh_user,
+                                      const float *w1_self_item, const float *w1_neigh_item,
+                                      float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
+                                      void *stream) {
+    if (n_pairs < 0 || n0 < 1) return gs::fail(GS_EINVAL, "gs_sage2_backward_tail: n_pairs=%lld n0=%d", (long long)n_pairs, n0);
+    if ((H1 != 32 && H1 != 64) || H2 < 2 || H2 > kMaxH || (H2 & 1))
+        return gs::fail(GS_ELIMIT, "gs_sage2_backward_tail: H1=%d (32 or 64) H2=%d (even, at most %d)", H1, H2, kMaxH);
+    if (act != GS_ACT_LINEAR && act != GS_ACT_RELU) return gs::fail(GS_EINVAL, "gs_sage2_backward_tail: unknown activation %d", act);
+    if (n_pairs == 0) return GS_OK;
+    if (!z_user || !z_item || !g_emb_user || !g_emb_item || !w1_self_user || !w1_neigh_user || !w1_self_item ||
+        !w1_neigh_item || !g_z_user || !g_z_item || !g_h1_user || !g_h1_item)
+        return gs::fail(GS_EINVAL, "gs_sage2_backward_tail: null pointer argument");
+    if (n_pairs > ((int64_t)1 << 40) / (1 + n0)) return gs::fail(GS_ELIMIT, "gs_sage2_backward_tail: n_pairs=%lld too large", (long long)n_pairs);
+    TailArgs a{};
+    a.z[0] = z_user; a.z[1] = z_item; a.g_emb[0] = g_emb_user; a.g_emb[1] = g_emb_item;
+    a.w_self[0] = w1_self_user; a.w_neigh[0] = w1_neigh_user; a.w_self[1] = w1_self_item; a.w_neigh[1] = w1_neigh_item;
+    a.g_z[0] = g_z_user; a.g_z[1] = g_z_item; a.g_h1[0] = g_h1_user; a.g_h1[1] = g_h1_item;
+    a.n_pairs = n_pairs; a.n0 = n0; a.H1 = H1; a.H2 = H2; a.normalize = normalize != 0; a.relu = act == GS_ACT_RELU;
+    int64_t blocks = (2 * n_pairs + kWaves - 1) / kWaves;
+    if (blocks > 512) blocks = 512;
+    const size_t lds = (size_t)(4 * (H2 / 2) * H1 + kWaves * kMaxH) * sizeof(float);        // at most 36 KB
+    hipLaunchKernelGGL(sage2_tail_bwd_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, a);
+    return gs::check_launch("gs_sage2_backward_tail");
+}

@@ -344,6 +344,32 @@ def l2_normalize_bwd(x, g_out, g_x=None):
     return g_x
 
 
+def sage2_backward_tail(z, g_emb, w1_self, w1_neigh, n0, normalize, act, g_z, g_h1):
+    """``gs_sage2_backward_tail``: every argument but the scalars is a dict by node
+    type.  ``z`` / ``g_emb`` / ``g_z`` are (B, H2), ``w1_*`` (H1, H2/2), ``g_h1``
+    (B * (1 + n0), H1) in the row layout of the one-kernel forward's saved tables."""
+    lib = load()
+    types = ('user', 'item')
+    b, h2 = z['user'].shape
+    h1 = w1_self['user'].shape[0]
+    for t in types:
+        for name, d, shape in (('z', z, (b, h2)), ('g_emb', g_emb, (b, h2)), ('g_z', g_z, (b, h2)),
+                               ('w1_self', w1_self, (h1, h2 // 2)), ('w1_neigh', w1_neigh, (h1, h2 // 2)),
+                               ('g_h1', g_h1, (b * (1 + int(n0)), h1))):
+            _dev(d[t], torch.float32, '%s[%s]' % (name, t), 2)
+            if tuple(d[t].shape) != shape:
+                raise ValueError("%s[%s] must be %s (got %s)" % (name, t, shape, tuple(d[t].shape)))
+    check(lib.gs_sage2_backward_tail(ptr(z['user']), ptr(z['item']), ptr(g_emb['user']), ptr(g_emb['item']),
+                                     b, int(n0), h1, h2, int(bool(normalize)), ACT[act],
+                                     ptr(w1_self['user']), ptr(w1_neigh['user']), ptr(w1_self['item']), ptr(w1_neigh['item']),
+                                     ptr(g_z['user']), ptr(g_z['item']), ptr(g_h1['user']), ptr(g_h1['item']),
+                                     stream_handle()), 'gs_sage2_backward_tail')
+
+
+def sage2_backward_tail_supported(h1, h2):
+    return h1 in (32, 64) and h2 % 2 == 0 and 2 <= h2 <= 64
+
+
 def fused_supported(fs, fn, h, max_child):
     return bool(load().gs_sage_fused_supported(int(fs), int(fn), int(h), int(max_child)))
 

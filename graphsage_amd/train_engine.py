@@ -64,6 +64,9 @@ class SageTrainEngine(SageForwardEngine):
         self.walk_train = bool(self.n_hops == 2 and kernels.sage2_supported(
             f['user'], f['item'], m.dims[1]['user'], m.dims[2]['user'], *self.fanouts))
         self._walk_train_call = None
+        # ... and then the top of the backward pass in one kernel as well (see _backward_walks)
+        self.tail_kernel = self.walk_train and kernels.sage2_backward_tail_supported(m.dims[1]['user'], m.dims[2]['user'])
+        self._side2 = None
 
     def _forward_walks_train(self, seeds, walk_ids, rng_seed, replay):
         m = self.model
@@ -167,6 +170,45 @@ class SageTrainEngine(SageForwardEngine):
         return self.g_xs[layer][t]
 
     # ---- backward -----------------------------------------------------------------
+    def _backward_walks(self, g_user, g_item, main):
+        """Two hops on the one-kernel forward's tables: one launch takes the embedding
+        gradients through the l2 normalisation, the layer-1 input gradients and the
+        neighbor-mean broadcast for both node types; after it only weight gradients
+        are left, and none of them waits for another: layer 0 of the user side on
+        the caller's stream, of the item side on a second, the two small layer-1
+        ones on a third."""
+        m = self.model
+        if self._side2 is None:
+            self._side2 = torch.cuda.Stream()
+        top = m._aggs[1]
+        kernels.sage2_backward_tail(self.z, {'user': g_user.contiguous(), 'item': g_item.contiguous()},
+                                    {t: top[t].w_self for t in _TYPES}, {t: top[t].w_neigh for t in _TYPES},
+                                    self.fanouts[0], m.normalize == "l2", top['user'].activation, self.g_z, self.g_h[0])
+        self._side.wait_stream(main)
+        self._side2.wait_stream(main)
+
+        def weight_grads(layer, t, x_self, x_mean, out, g_out):
+            agg = m._aggs[layer][t]
+            for p in agg.parameters():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            kernels.sage_project_bwd(x_self, x_mean, agg.w_self, agg.w_neigh, agg.activation, out, g_out,
+                                     need_x_self=False, need_x_mean=False, need_bias=agg.bias is not None,
+                                     g_w_self=agg.w_self.grad, g_w_neigh=agg.w_neigh.grad,
+                                     g_bias=None if agg.bias is None else agg.bias.grad, workspace=self.ws[layer][t])
+
+        for t, stream in (('user', main), ('item', self._side)):
+            with torch.cuda.stream(stream):
+                rows = self.h[0][t].shape[0]
+                weight_grads(0, t, self.x_self[t], self.x_mean[0][t][:rows], self.h[0][t], self.g_h[0][t])
+        with torch.cuda.stream(self._side2):
+            for t in _TYPES:
+                weight_grads(1, t, self.h[0][t][:self.batch], self.x_mean[1][t][:self.batch], self.z[t], self.g_z[t])
+        main.wait_stream(self._side)
+        main.wait_stream(self._side2)
+        if self._padded_model is not None:
+            self._padded_model.scatter_grads()
+
     def backward(self, g_user, g_item):
         """Gradients of every aggregator weight from the embedding gradients; they
         are written into ``param.grad`` (which must exist, e.g. as views of a
@@ -181,6 +223,8 @@ class SageTrainEngine(SageForwardEngine):
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
+        if self.tail_kernel:
+            return self._backward_walks(g_user, g_item, main)
         streams = {'user': main, 'item': self._side}
         g_emb = {'user': g_user.contiguous(), 'item': g_item.contiguous()}
         g_out = {}

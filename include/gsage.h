@@ -322,6 +322,32 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
                      const gs_sage2_saved *saved, int32_t *err_flag, void *stream);
 
 /*
+ * Backward of the top of that model, one launch for both node types: from the
+ * gradients of the embeddings to the gradients of the layer-0 activations, in
+ * the row layout of the gs_sage2_saved tables; index 0 / "_user" = user,
+ * 1 / "_item" = item, o = the other type:
+ *   g_z[t][p, :]             = gradient at z[t][p, :] of the l2 normalisation
+ *                              (models.py:32; copied through when normalize == 0)
+ *   g_h1[t][p, :]            = act'(z) * g_z[t][p, :H2/2] . w1_self[t]^T
+ *                              (utils.py:109-119: the root's own layer-1 input)
+ *   g_h1[o][n_pairs + p*n0 + j, :] = act'(z) * g_z[t][p, H2/2:] . w1_neigh[t]^T / n0,  j < n0
+ *                              (utils.py:103-109: the mean over the root's n0 hop-1 heads)
+ * Both g_h1 tables ([n_pairs * (1 + n0), H1]) are written completely.  It is
+ * gs_l2_normalize_bwd + the input gradients of gs_sage_project_bwd +
+ * gs_gather_mean_bwd of the layer-1 backward in one kernel; the layer-1 weight
+ * gradients follow from g_z through gs_sage_project_bwd as usual.
+ * w1_* are the layer-1 weights [H1, H2/2]; act is the layer-1 activation (z is
+ * its output).  H1 is 32 or 64, H2 even and at most 64, else GS_ELIMIT.
+ */
+int gs_sage2_backward_tail(const float *z_user, const float *z_item,
+                           const float *g_emb_user, const float *g_emb_item,
+                           int64_t n_pairs, int n0, int H1, int H2, int normalize, int act,
+                           const float *w1_self_user, const float *w1_neigh_user,
+                           const float *w1_self_item, const float *w1_neigh_item,
+                           float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
+                           void *stream);
+
+/*
  * Link head of the reference's training script: concat(user_emb, item_emb) ->
  * Dense(1, sigmoid) (link_utils.py:167-168,244-247 as used at
  * train_movielens.py:179), kernel device float[2E], bias device float[1].

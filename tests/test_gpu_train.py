@@ -361,3 +361,61 @@ def test_plan_step_without_bias_and_normalisation_equals_autograd(cuda):
     (l0, g0), (l1, g1) = results
     assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0))
     assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
+
+
+@pytest.mark.parametrize('b,n0,h1,h2,normalize,act', [(48, 8, 32, 32, True, 'linear'), (5, 25, 64, 64, True, 'linear'),
+                                                      (130, 3, 32, 64, False, 'relu'), (1, 1, 64, 32, True, 'relu'),
+                                                      (4096, 25, 32, 32, True, 'linear')])
+def test_backward_tail_kernel_equals_the_layer_by_layer_kernels(cuda, b, n0, h1, h2, normalize, act):
+    """gs_sage2_backward_tail against gs_l2_normalize_bwd + the input gradients of
+    gs_sage_project_bwd + gs_gather_mean_bwd on the same inputs, both node types."""
+    from graphsage_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(b + n0)
+    rnd = lambda *shape: torch.randn(shape, device=cuda, generator=gen)
+    types = ('user', 'item')
+    other = {'user': 'item', 'item': 'user'}
+    z = {t: rnd(b, h2) for t in types}
+    if normalize:
+        z['user'][0] = 0.0                                   # a zero row: the normalisation's guard
+    g_emb = {t: rnd(b, h2) for t in types}
+    ws = {t: rnd(h1, h2 // 2) * 0.2 for t in types}
+    wn = {t: rnd(h1, h2 // 2) * 0.2 for t in types}
+    g_z = {t: torch.empty(b, h2, device=cuda) for t in types}
+    g_h1 = {t: torch.full((b * (1 + n0), h1), float('nan'), device=cuda) for t in types}
+    kernels.sage2_backward_tail(z, g_emb, ws, wn, n0, normalize, act, g_z, g_h1)
+    for t in types:
+        want_gz = kernels.l2_normalize_bwd(z[t], g_emb[t]) if normalize else g_emb[t]
+        row_scale = want_gz.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)     # (fused multiply-adds round differently)
+        assert float(((g_z[t] - want_gz).abs() / row_scale).max()) <= 2e-6
+        x = torch.zeros(b, h1, device=cuda)                  # the weight-gradient inputs do not matter here
+        _, _, _, gxs, gxm = kernels.sage_project_bwd(x, x, ws[t], wn[t], act, z[t], g_z[t], need_bias=False)
+        scale = max(1.0, float(gxs.abs().max()), float(gxm.abs().max()))
+        assert float((g_h1[t][:b] - gxs).abs().max()) <= 2e-6 * scale
+        spread = torch.empty(b * n0, h1, device=cuda)
+        kernels.gather_mean_bwd(gxm, None, n0, spread)
+        assert float((g_h1[other[t]][b:] - spread).abs().max()) <= 2e-6 * scale
+    assert not any(bool(torch.isnan(g_h1[t]).any()) for t in types)   # every row written
+
+
+def test_plan_backward_with_and_without_the_tail_kernel(cuda):
+    """A two-hop training step through the one-launch top of the backward pass and through the
+    layer-by-layer kernels: same loss, same gradients."""
+    from graphsage_amd.train import LinkHead
+    g, links, targets = _toy(5, fu=64, fi=64)
+    b, ns, sizes = 40, [6, 3], [32, 32]
+    grads = []
+    for tail in (True, False):
+        gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+        model = ga.GraphSAGE(sizes, gen, seed=11)
+        model.build()
+        tr = Trainer(model, head=LinkHead(sizes[-1], cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
+        assert tr.engine.tail_kernel
+        tr.engine.tail_kernel = tail
+        lk = np.asarray(links[:b])
+        seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+        loss, _ = tr.step_device(seeds, torch.from_numpy(targets[:b]).to(cuda),
+                                 torch.arange(2 * b, dtype=torch.int64, device=cuda), rng_seed=9)
+        grads.append((float(loss), tr.bucket.flat.clone()))
+    assert grads[0][0] == grads[1][0]
+    scale = float(grads[1][1].abs().max())
+    assert float((grads[0][1] - grads[1][1]).abs().max()) <= 2e-6 * scale
