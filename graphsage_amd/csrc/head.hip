@@ -121,6 +121,20 @@ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__re
     }
 }
 
+// One step's inputs into the buffers a captured graph reads, and the step's learning rate: four
+// small device copies in one launch.
+__global__ __launch_bounds__(kThreads)
+void stage_batch_kernel(const int32_t *__restrict__ seeds, int32_t *__restrict__ seeds_dst, int64_t n_seeds,
+                        const int64_t *__restrict__ walks, int64_t *__restrict__ walks_dst, int64_t n_walks,
+                        const float *__restrict__ targets, float *__restrict__ targets_dst, int64_t n_targets,
+                        float lr_t, float *__restrict__ lr_dst) {
+    const int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = i0; i < n_seeds; i += stride) seeds_dst[i] = seeds[i];
+    for (int64_t i = i0; i < n_walks; i += stride) walks_dst[i] = walks[i];
+    for (int64_t i = i0; i < n_targets; i += stride) targets_dst[i] = targets[i];
+    if (i0 == 0 && lr_dst) lr_dst[0] = lr_t;
+}
+
 inline int head_blocks(int64_t B) {
     int64_t b = (B + 15) / 16;               // four waves per block, a few rows per wave
     if (b < 1) b = 1;
@@ -179,4 +193,24 @@ extern "C" int gs_adam_step(float *params, const float *grads, float *m, float *
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, params, grads, m, v, n,
                        lr_t, lr_t_device, beta1, beta2, eps);
     return gs::check_launch("gs_adam_step");
+}
+
+extern "C" int gs_stage_batch(const int32_t *seeds, int32_t *seeds_dst, int64_t n_seeds,
+                              const int64_t *walk_ids, int64_t *walk_ids_dst, int64_t n_walk_ids,
+                              const float *targets, float *targets_dst, int64_t n_targets,
+                              float lr_t, float *lr_t_dst, void *stream) {
+    if (n_seeds < 0 || n_walk_ids < 0 || n_targets < 0)
+        return gs::fail(GS_EINVAL, "gs_stage_batch: counts %lld %lld %lld", (long long)n_seeds, (long long)n_walk_ids, (long long)n_targets);
+    if ((n_seeds && (!seeds || !seeds_dst)) || (n_walk_ids && (!walk_ids || !walk_ids_dst)) || (n_targets && (!targets || !targets_dst)))
+        return gs::fail(GS_EINVAL, "gs_stage_batch: null pointer argument");
+    int64_t n = n_seeds > n_walk_ids ? n_seeds : n_walk_ids;
+    if (n_targets > n) n = n_targets;
+    if (n == 0 && !lr_t_dst) return GS_OK;
+    int64_t blocks = (n + kThreads - 1) / kThreads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(stage_batch_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream,
+                       seeds, seeds_dst, n_seeds, walk_ids, walk_ids_dst, n_walk_ids, targets, targets_dst, n_targets,
+                       lr_t, lr_t_dst);
+    return gs::check_launch("gs_stage_batch");
 }

@@ -620,3 +620,21 @@ def adam_step(params_flat, grads_flat, m, v, lr_t, beta1, beta2, eps, lr_t_devic
             raise ValueError("flat optimizer buffers differ in length")
     check(lib.gs_adam_step(ptr(params_flat), ptr(grads_flat), ptr(m), ptr(v), params_flat.numel(), float(lr_t),
                            ptr(lr_t_device), float(beta1), float(beta2), float(eps), stream_handle()), 'gs_adam_step')
+
+
+def stage_batch(seeds, seeds_dst, walk_ids, walk_ids_dst, targets, targets_dst, lr_t=0.0, lr_dst=None):
+    """``gs_stage_batch``: a step's inputs into the buffers its captured graph reads
+    (and the step's Adam rate into ``lr_dst``), one launch.  Sources must already
+    have the destination's dtype, length and device."""
+    lib = load()
+    for (src, dst, dtype, name) in ((seeds, seeds_dst, torch.int32, 'seeds'), (walk_ids, walk_ids_dst, torch.int64, 'walk_ids'),
+                                    (targets, targets_dst, torch.float32, 'targets')):
+        _dev(src, dtype, name)
+        _dev(dst, dtype, name + '_dst')
+        if src.numel() != dst.numel():
+            raise ValueError("%s has %d elements, its buffer %d" % (name, src.numel(), dst.numel()))
+    if lr_dst is not None:
+        _dev(lr_dst, torch.float32, 'lr_dst')
+    check(lib.gs_stage_batch(ptr(seeds), ptr(seeds_dst), seeds.numel(), ptr(walk_ids), ptr(walk_ids_dst), walk_ids.numel(),
+                             ptr(targets), ptr(targets_dst), targets.numel(), float(lr_t), ptr(lr_dst), stream_handle()),
+          'gs_stage_batch')

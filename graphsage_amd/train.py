@@ -109,12 +109,17 @@ class Adam:
         self.v = torch.zeros_like(grads_flat)
         self.t = 0
 
+    def next_rate(self):
+        """Counts a step and returns its bias-corrected rate (for a caller that
+        hands the rate to a replayed graph itself)."""
+        self.t += 1
+        return self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+
     @torch.no_grad()
     def step(self, launch=True):
         """launch=False only refreshes the device-side rate (the update kernel
         itself is then part of a replayed HIP graph)."""
-        self.t += 1
-        lr_t = self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        lr_t = self.next_rate()
         if self.p_flat is not None and self.g.is_cuda:
             from . import kernels
             if self.lr_dev is not None:                  # graph replay: the rate travels through memory
@@ -254,15 +259,24 @@ class Trainer:
             torch.cuda.synchronize()
             with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
                 self._graph_body(not multi)
-        eng.seeds_buf.copy_(seeds)
-        self._walk_buf.copy_(walk_ids)
-        self._target_buf.copy_(targets)
+        def fits(src, dst):
+            return (isinstance(src, torch.Tensor) and src.device == dst.device and src.dtype == dst.dtype
+                    and src.is_contiguous() and src.numel() == dst.numel())
+        if fits(seeds, eng.seeds_buf) and fits(walk_ids, self._walk_buf) and fits(targets, self._target_buf):
+            # the usual case (rows of an epoch staged on the device): inputs and rate in one launch
+            kernels.stage_batch(seeds, eng.seeds_buf, walk_ids, self._walk_buf, targets, self._target_buf,
+                                0.0 if multi else self.opt.next_rate(), None if multi else self.opt.lr_dev)
+        else:
+            eng.seeds_buf.copy_(seeds)
+            self._walk_buf.copy_(walk_ids)
+            self._target_buf.copy_(targets)
+            if not multi:
+                self.opt.step(launch=False)              # sets the device-side rate for this step
         if multi:
             self._graph.replay()
             self.bucket.all_reduce_mean(self.group)
             self.opt.step()
         else:
-            self.opt.step(launch=False)                  # sets the device-side rate for this step
             self._graph.replay()
         return self._head_step.loss, self._head_step.pred.reshape(-1, 1)
 

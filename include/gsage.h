@@ -379,6 +379,18 @@ int gs_link_head_mse_fwd_bwd(const float *emb_user, const float *emb_item, int64
 int gs_adam_step(float *params, const float *grads, float *m, float *v, int64_t n,
                  float lr_t, const float *lr_t_device, float beta1, float beta2, float eps, void *stream);
 
+/*
+ * Hands one batch to a step whose launches are replayed from a captured graph:
+ * the batch's roots, walk ids and targets (what LinkSequence.__getitem__ slices
+ * out of the epoch, generator.py:84-98) are copied into the fixed buffers the
+ * graph reads, and the step's Adam rate into lr_t_dst (nullable), in one launch
+ * instead of four small copies.  A group with count 0 is skipped.
+ */
+int gs_stage_batch(const int32_t *seeds, int32_t *seeds_dst, int64_t n_seeds,
+                   const int64_t *walk_ids, int64_t *walk_ids_dst, int64_t n_walk_ids,
+                   const float *targets, float *targets_dst, int64_t n_targets,
+                   float lr_t, float *lr_t_dst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -419,3 +419,21 @@ def test_plan_backward_with_and_without_the_tail_kernel(cuda):
     assert grads[0][0] == grads[1][0]
     scale = float(grads[1][1].abs().max())
     assert float((grads[0][1] - grads[1][1]).abs().max()) <= 2e-6 * scale
+
+
+def test_stage_batch_copies_inputs_and_rate_in_one_launch(cuda):
+    from graphsage_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    for b in (1, 100, 5000):
+        seeds = torch.randint(0, 1 << 30, (2 * b,), device=cuda, generator=gen, dtype=torch.int32)
+        walks = torch.randint(0, 1 << 60, (2 * b,), device=cuda, generator=gen, dtype=torch.int64)
+        y = torch.rand(b, device=cuda, generator=gen)
+        d_seeds, d_walks, d_y = torch.zeros_like(seeds), torch.zeros_like(walks), torch.zeros_like(y)
+        lr = torch.zeros(1, device=cuda)
+        kernels.stage_batch(seeds, d_seeds, walks, d_walks, y, d_y, 0.125, lr)
+        assert torch.equal(d_seeds, seeds) and torch.equal(d_walks, walks) and torch.equal(d_y, y)
+        assert float(lr) == 0.125
+    with pytest.raises(ValueError):
+        kernels.stage_batch(seeds[:4], d_seeds, walks, d_walks, y, d_y)
+    with pytest.raises(TypeError):
+        kernels.stage_batch(seeds.long(), d_seeds, walks, d_walks, y, d_y)
