@@ -60,6 +60,15 @@ SIGNATURES['gs_sage_fused_fwd'] = (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _i32
 
 
 
+class WgradProblem(_c.Structure):
+    """gs_wgrad_problem of include/gsage.h."""
+    _fields_ = [('x_self', _vp), ('x_mean', _vp), ('out', _vp), ('g_out', _vp), ('g_W_self', _vp), ('g_W_neigh', _vp),
+                ('g_bias', _vp), ('workspace', _vp), ('workspace_bytes', _sz)]
+
+
+SIGNATURES['gs_sage_project_wgrad_pair'] = (_i32, [_c.POINTER(WgradProblem), _c.POINTER(WgradProblem),
+                                                   _i32, _i32, _i64, _i32, _i32, _vp])
+
 class SageWeights(_c.Structure):
     """gs_sage_weights of include/gsage.h."""
     _fields_ = [('w_self', _vp), ('w_neigh', _vp), ('bias', _vp)]

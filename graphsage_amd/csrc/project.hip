@@ -708,7 +708,7 @@ inline bool wgrad_big_applies(int Fs, int Fn, int Hh, int H, const void *xs, con
     return Fs % 128 == 0 && Fn % 128 == 0 && Hh % 128 == 0 && H % 4 == 0 && al16(xs) && al16(xm) && al16(g) && (!mask || al16(mask));
 }
 
-// Adds the per-chunk slabs of both halves in one launch (blockIdx.y = half).  Element e is summed
+// Adds the per-chunk slabs of both halves (of one or two problem instances) in one launch (blockIdx.y = side).  Element e is summed
 // by sixteen threads that take chunks c = j, j+16, ... each in increasing order; their partial
 // sums are then added in index order: the result does not depend on scheduling.
 struct ReduceSide {
@@ -717,14 +717,18 @@ struct ReduceSide {
     int K;
 };
 
+struct ReduceSides {
+    ReduceSide s[4];                           // blockIdx.y picks one (two halves of one or two problem instances)
+};
+
 __global__ __launch_bounds__(kThreads)
-void wgrad_reduce_kernel(ReduceSide s0, ReduceSide s1, int n_chunks, int N) {
+void wgrad_reduce_kernel(const ReduceSides sides, int n_chunks, int N) {
     __shared__ float part[kThreads];
-    const bool second = blockIdx.y == 1;
-    const float *__restrict__ slab = second ? s1.slab : s0.slab;
-    float *__restrict__ gW = second ? s1.gW : s0.gW;
-    float *__restrict__ gbias = second ? s1.gbias : s0.gbias;
-    const int K = second ? s1.K : s0.K;
+    const ReduceSide &sd = sides.s[blockIdx.y];
+    const float *__restrict__ slab = sd.slab;
+    float *__restrict__ gW = sd.gW;
+    float *__restrict__ gbias = sd.gbias;
+    const int K = sd.K;
     const int total = (K + 1) * N;
     const int e = blockIdx.x * 16 + (threadIdx.x & 15);
     const int j = threadIdx.x >> 4;
@@ -762,12 +766,25 @@ template <> struct XVec<8> { float v[8]; __device__ __forceinline__ void load(co
 
 constexpr int WD_UNROLL = 4;            // MFMA steps (of four rows) whose loads are in flight together
 
+// One problem instance: inputs, output gradient, relu mask (or NULL), the two slab arrays.
+struct WgradDirectSide {
+    const float *Xs, *Xn, *G, *Mk;
+    float *slab_s, *slab_n;
+};
+
+// blockIdx.y picks the instance: the two node types of a layer have the same shapes, and one launch
+// over both costs no fork and join of streams.
 template <int KS, int KN, int NT>
 __global__ __launch_bounds__(kThreads)
-void wgrad_direct_kernel(const float *__restrict__ Xs, const float *__restrict__ Xn,
-                         const float *__restrict__ G, const float *__restrict__ Mk, int64_t M,
-                         int64_t rows_per_block, float *__restrict__ slab_s, float *__restrict__ slab_n) {
+void wgrad_direct_kernel(const WgradDirectSide p0, const WgradDirectSide p1, int64_t M, int64_t rows_per_block) {
     constexpr int VS = KS / 16, VN = KN / 16, HH = NT * 16, H = 2 * HH;
+    const bool second = blockIdx.y != 0;
+    const float *__restrict__ Xs = second ? p1.Xs : p0.Xs;
+    const float *__restrict__ Xn = second ? p1.Xn : p0.Xn;
+    const float *__restrict__ G = second ? p1.G : p0.G;
+    const float *__restrict__ Mk = second ? p1.Mk : p0.Mk;
+    float *__restrict__ slab_s = second ? p1.slab_s : p0.slab_s;
+    float *__restrict__ slab_n = second ? p1.slab_n : p0.slab_n;
     constexpr int kSlabS = (KS + 1) * HH, kSlabN = (KN + 1) * HH;
     __shared__ float red[kSlabS + kSlabN];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -880,13 +897,20 @@ inline int64_t wgrad_direct_rows(int64_t M) {
     return rpb < 128 ? 128 : rpb;
 }
 
-inline bool launch_wgrad_direct(int Fs, int Fn, int Hh, const float *xs, const float *xn, const float *g,
-                                const float *mask, int64_t M, int64_t rpb, int64_t nblocks, float *slab_s,
-                                float *slab_n, hipStream_t s) {
+inline bool wgrad_direct_covers(int Fs, int Fn, int Hh) {
+#define GS_CASE(KS_, KN_, NT_) if (Fs == KS_ && Fn == KN_ && Hh == NT_ * 16) return true;
+    GS_WGRAD_DIRECT_CASES(GS_CASE)
+#undef GS_CASE
+    return false;
+}
+
+// n_sides (1 or 2) problem instances of one shape in one launch
+inline bool launch_wgrad_direct(int Fs, int Fn, int Hh, const WgradDirectSide &p0, const WgradDirectSide &p1, int n_sides,
+                                int64_t M, int64_t rpb, int64_t nblocks, hipStream_t s) {
 #define GS_CASE(KS_, KN_, NT_)                                                                              \
     if (Fs == KS_ && Fn == KN_ && Hh == NT_ * 16) {                                                         \
-        hipLaunchKernelGGL((wgrad_direct_kernel<KS_, KN_, NT_>), dim3((unsigned)nblocks), dim3(kThreads), 0, s, \
-                           xs, xn, g, mask, M, rpb, slab_s, slab_n);                                        \
+        hipLaunchKernelGGL((wgrad_direct_kernel<KS_, KN_, NT_>), dim3((unsigned)nblocks, (unsigned)n_sides), \
+                           dim3(kThreads), 0, s, p0, p1, M, rpb);                                           \
         return true;                                                                                        \
     }
     GS_WGRAD_DIRECT_CASES(GS_CASE)
@@ -1024,7 +1048,7 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
                                    float *g_x_self, float *g_x_mean,
                                    void *workspace, size_t workspace_bytes, void *stream) {
     if (int rc = check_project_shape("gs_sage_project_bwd", Fs, Fn, M, H, act)) return rc;
-    if (M > 0 && (!x_self || !x_mean || !W_self || !W_neigh || !g_out))
+    if (M > 0 && (!x_self || !x_mean || !g_out || ((g_x_self || g_x_mean) && (!W_self || !W_neigh))))
         return gs::fail(GS_EINVAL, "gs_sage_project_bwd: null pointer argument");
     if (M > 0 && act == GS_ACT_RELU && !out) return gs::fail(GS_EINVAL, "gs_sage_project_bwd: relu needs the forward output");
     const int Hh = H / 2;
@@ -1056,7 +1080,8 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
             const int64_t rpb = wgrad_direct_rows(M);
             const int64_t nblocks = (M + rpb - 1) / rpb;          // <= nc: the slabs fit the workspace
             slab1 = slab0 + (size_t)nblocks * (Fs + 1) * Hh;
-            direct = launch_wgrad_direct(Fs, Fn, Hh, x_self, x_mean, g_out, mask, M, rpb, nblocks, slab0, slab1, s);
+            const WgradDirectSide side{x_self, x_mean, g_out, mask, slab0, slab1};
+            direct = launch_wgrad_direct(Fs, Fn, Hh, side, side, 1, M, rpb, nblocks, s);
             if (direct) {
                 if (int rc = gs::check_launch("gs_sage_project_bwd (wgrad)")) return rc;
                 nc = nblocks;
@@ -1078,9 +1103,11 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
             if (int rc = gs::check_launch("gs_sage_project_bwd (wgrad)")) return rc;
         }
         // bias gradient: row Fs of the self slab holds columns 0..Hh-1, row Fn of the neighbor slab Hh..H-1
-        ReduceSide r0{slab0, g_W_self, g_bias, Fs}, r1{slab1, g_W_neigh, g_bias ? g_bias + Hh : nullptr, Fn};
+        ReduceSides rs{};
+        rs.s[0] = ReduceSide{slab0, g_W_self, g_bias, Fs};
+        rs.s[1] = ReduceSide{slab1, g_W_neigh, g_bias ? g_bias + Hh : nullptr, Fn};
         const int tot = ((Fs > Fn ? Fs : Fn) + 1) * Hh;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 15) / 16), 2), dim3(kThreads), 0, s, r0, r1, (int)nc, Hh);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 15) / 16), 2), dim3(kThreads), 0, s, rs, (int)nc, Hh);
         if (int rc = gs::check_launch("gs_sage_project_bwd (reduce)")) return rc;
     }
 
@@ -1112,6 +1139,62 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
         if (int rc = gs::check_launch("gs_sage_project_bwd (dx)")) return rc;
     }
     return GS_OK;
+}
+
+// Weight and bias gradients of two projections of one shape (the two node types of a layer) with one
+// weight-gradient launch and one reduction launch; falls back to two gs_sage_project_bwd calls when
+// the shape has no direct kernel.
+extern "C" int gs_sage_project_wgrad_pair(const gs_wgrad_problem *a, const gs_wgrad_problem *b,
+                                          int Fs, int Fn, int64_t M, int H, int act, void *stream) {
+    if (int rc = check_project_shape("gs_sage_project_wgrad_pair", Fs, Fn, M, H, act)) return rc;
+    if (!a || !b) return gs::fail(GS_EINVAL, "gs_sage_project_wgrad_pair: null problem");
+    const gs_wgrad_problem *pr[2] = {a, b};
+    const size_t need = gs_sage_project_bwd_workspace(Fs, Fn, H, M);
+    bool direct = M > 0 && wgrad_direct_covers(Fs, Fn, H / 2) && !wgrad_big_applies(Fs, Fn, H / 2, H, a->x_self, a->x_mean, a->g_out, nullptr);
+    for (int i = 0; i < 2; ++i) {
+        const gs_wgrad_problem &p = *pr[i];
+        if (M > 0 && (!p.x_self || !p.x_mean || !p.g_out || !p.g_W_self || !p.g_W_neigh))
+            return gs::fail(GS_EINVAL, "gs_sage_project_wgrad_pair: null pointer in problem %d", i);
+        if (M > 0 && act == GS_ACT_RELU && !p.out)
+            return gs::fail(GS_EINVAL, "gs_sage_project_wgrad_pair: relu needs the forward output (problem %d)", i);
+        if (M > 0 && (!p.workspace || p.workspace_bytes < need))
+            return gs::fail(GS_EINVAL, "gs_sage_project_wgrad_pair: workspace of %zu bytes needed, %zu given (problem %d)",
+                            need, p.workspace_bytes, i);
+        const float *mask = act == GS_ACT_RELU ? p.out : nullptr;
+        direct = direct && aligned16(p.x_self) && aligned16(p.x_mean) && aligned16(p.g_out) && (!mask || aligned16(mask));
+    }
+    if (M == 0) return GS_OK;
+    if (!direct) {
+        for (int i = 0; i < 2; ++i) {
+            const gs_wgrad_problem &p = *pr[i];
+            // (no input gradients are asked for, so the weights are not read)
+            if (int rc = gs_sage_project_bwd(p.x_self, Fs, p.x_mean, Fn, M, nullptr, nullptr, H, act, p.out, p.g_out,
+                                             p.g_W_self, p.g_W_neigh, p.g_bias, nullptr, nullptr,
+                                             p.workspace, p.workspace_bytes, stream))
+                return rc;
+        }
+        return GS_OK;
+    }
+    const int Hh = H / 2;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rpb = wgrad_direct_rows(M);
+    const int64_t nblocks = (M + rpb - 1) / rpb;                  // at most the chunk count the workspaces are sized for
+    WgradDirectSide sd[2];
+    ReduceSides rs{};
+    for (int i = 0; i < 2; ++i) {
+        const gs_wgrad_problem &p = *pr[i];
+        float *slab0 = static_cast<float *>(p.workspace);
+        float *slab1 = slab0 + (size_t)nblocks * (Fs + 1) * Hh;
+        sd[i] = WgradDirectSide{p.x_self, p.x_mean, p.g_out, act == GS_ACT_RELU ? p.out : nullptr, slab0, slab1};
+        rs.s[2 * i] = ReduceSide{slab0, p.g_W_self, p.g_bias, Fs};
+        rs.s[2 * i + 1] = ReduceSide{slab1, p.g_W_neigh, p.g_bias ? p.g_bias + Hh : nullptr, Fn};
+    }
+    if (!launch_wgrad_direct(Fs, Fn, Hh, sd[0], sd[1], 2, M, rpb, nblocks, s))
+        return gs::fail(GS_ELIMIT, "gs_sage_project_wgrad_pair: no kernel for Fs=%d Fn=%d H=%d", Fs, Fn, H);
+    if (int rc = gs::check_launch("gs_sage_project_wgrad_pair (wgrad)")) return rc;
+    const int tot = ((Fs > Fn ? Fs : Fn) + 1) * Hh;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 15) / 16), 4), dim3(kThreads), 0, s, rs, (int)nblocks, Hh);
+    return gs::check_launch("gs_sage_project_wgrad_pair (reduce)");
 }
 
 extern "C" int gs_l2_normalize_fwd(const float *x, int64_t M, int H, float *out, void *stream) {

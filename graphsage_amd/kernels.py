@@ -344,6 +344,51 @@ def l2_normalize_bwd(x, g_out, g_x=None):
     return g_x
 
 
+class WgradPairCall:
+    """A prepared ``gs_sage_project_wgrad_pair`` call: weight and bias gradients of
+    two projections of one shape (the two node types of a layer), checked once,
+    enqueued by ``run()``.  Each problem is a dict with x_self, x_mean, out (or
+    None), g_out, g_w_self, g_w_neigh, g_bias (or None), workspace."""
+
+    def __init__(self, problems, act):
+        lib = load()
+        if len(problems) != 2:
+            raise ValueError("two problems expected")
+        m, fs = problems[0]['x_self'].shape
+        fn = problems[0]['x_mean'].shape[1]
+        h = problems[0]['g_out'].shape[1]
+        need = lib.gs_sage_project_bwd_workspace(fs, fn, h, m)
+        self._keep, self._structs = [], []
+        for p in problems:
+            for name, shape in (('x_self', (m, fs)), ('x_mean', (m, fn)), ('g_out', (m, h)), ('out', (m, h))):
+                if p.get(name) is None and name == 'out':
+                    continue
+                _dev(p[name], torch.float32, name, 2)
+                if tuple(p[name].shape) != shape:
+                    raise ValueError("%s must be %s (got %s)" % (name, shape, tuple(p[name].shape)))
+            for name, n in (('g_w_self', fs * (h // 2)), ('g_w_neigh', fn * (h // 2)), ('g_bias', h)):
+                if p.get(name) is None and name == 'g_bias':
+                    continue
+                _dev(p[name], torch.float32, name)
+                if p[name].numel() != n:
+                    raise ValueError("%s has %d elements, %d needed" % (name, p[name].numel(), n))
+            _dev(p['workspace'], torch.float32, 'workspace', 1)
+            if p['workspace'].numel() * 4 < need:
+                raise ValueError("workspace of %d bytes needed" % need)
+            if ACT[act] == ACT['relu'] and p.get('out') is None:
+                raise ValueError("relu needs the forward output")
+            self._keep.append(dict(p))
+            self._structs.append(_lib.WgradProblem(ptr(p['x_self']), ptr(p['x_mean']), ptr(p.get('out')), ptr(p['g_out']),
+                                                   ptr(p['g_w_self']), ptr(p['g_w_neigh']), ptr(p.get('g_bias')),
+                                                   ptr(p['workspace']), p['workspace'].numel() * 4))
+        self._args = (fs, fn, m, h, ACT[act])
+        self._lib = lib
+
+    def run(self):
+        check(self._lib.gs_sage_project_wgrad_pair(ctypes.byref(self._structs[0]), ctypes.byref(self._structs[1]),
+                                                   *self._args, stream_handle()), 'gs_sage_project_wgrad_pair')
+
+
 def sage2_backward_tail(z, g_emb, w1_self, w1_neigh, n0, normalize, act, g_z, g_h1):
     """``gs_sage2_backward_tail``: every argument but the scalars is a dict by node
     type.  ``z`` / ``g_emb`` / ``g_z`` are (B, H2), ``w1_*`` (H1, H2/2), ``g_h1``

@@ -67,6 +67,7 @@ class SageTrainEngine(SageForwardEngine):
         # ... and then the top of the backward pass in one kernel as well (see _backward_walks)
         self.tail_kernel = self.walk_train and kernels.sage2_backward_tail_supported(m.dims[1]['user'], m.dims[2]['user'])
         self._side2 = None
+        self._wgrad_pairs = None
 
     def _forward_walks_train(self, seeds, walk_ids, rng_seed, replay):
         m = self.model
@@ -174,9 +175,11 @@ class SageTrainEngine(SageForwardEngine):
         """Two hops on the one-kernel forward's tables: one launch takes the embedding
         gradients through the l2 normalisation, the layer-1 input gradients and the
         neighbor-mean broadcast for both node types; after it only weight gradients
-        are left, and none of them waits for another: layer 0 of the user side on
-        the caller's stream, of the item side on a second, the two small layer-1
-        ones on a third."""
+        are left, and none of them waits for another.  With equal feature widths
+        the two node types of a layer share one launch (layer 0 on the caller's
+        stream, the small layer 1 beside it); otherwise layer 0 of the user side
+        runs on the caller's stream, of the item side on a second, layer 1 on a
+        third."""
         m = self.model
         if self._side2 is None:
             self._side2 = torch.cuda.Stream()
@@ -184,30 +187,62 @@ class SageTrainEngine(SageForwardEngine):
         kernels.sage2_backward_tail(self.z, {'user': g_user.contiguous(), 'item': g_item.contiguous()},
                                     {t: top[t].w_self for t in _TYPES}, {t: top[t].w_neigh for t in _TYPES},
                                     self.fanouts[0], m.normalize == "l2", top['user'].activation, self.g_z, self.g_h[0])
-        self._side.wait_stream(main)
-        self._side2.wait_stream(main)
-
-        def weight_grads(layer, t, x_self, x_mean, out, g_out):
-            agg = m._aggs[layer][t]
-            for p in agg.parameters():
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-            kernels.sage_project_bwd(x_self, x_mean, agg.w_self, agg.w_neigh, agg.activation, out, g_out,
-                                     need_x_self=False, need_x_mean=False, need_bias=agg.bias is not None,
-                                     g_w_self=agg.w_self.grad, g_w_neigh=agg.w_neigh.grad,
-                                     g_bias=None if agg.bias is None else agg.bias.grad, workspace=self.ws[layer][t])
-
-        for t, stream in (('user', main), ('item', self._side)):
-            with torch.cuda.stream(stream):
-                rows = self.h[0][t].shape[0]
-                weight_grads(0, t, self.x_self[t], self.x_mean[0][t][:rows], self.h[0][t], self.g_h[0][t])
-        with torch.cuda.stream(self._side2):
-            for t in _TYPES:
-                weight_grads(1, t, self.h[0][t][:self.batch], self.x_mean[1][t][:self.batch], self.z[t], self.g_z[t])
-        main.wait_stream(self._side)
-        main.wait_stream(self._side2)
+        f = {t: self.x_self[t].shape[1] for t in _TYPES}
+        if f['user'] == f['item']:
+            # both node types of a layer have one shape: each layer's weight gradients are one launch (+ one
+            # reduction); layer 0 stays on the caller's stream, the small layer 1 goes beside it
+            if self._wgrad_pairs is None:
+                self._wgrad_pairs = [self._wgrad_pair(0), self._wgrad_pair(1)]
+            self._side2.wait_stream(main)
+            self._wgrad_pairs[0].run()
+            with torch.cuda.stream(self._side2):
+                self._wgrad_pairs[1].run()
+            main.wait_stream(self._side2)
+        else:
+            self._side.wait_stream(main)
+            self._side2.wait_stream(main)
+            for t, stream in (('user', main), ('item', self._side)):
+                with torch.cuda.stream(stream):
+                    self._weight_grads(0, t)
+            with torch.cuda.stream(self._side2):
+                for t in _TYPES:
+                    self._weight_grads(1, t)
+            main.wait_stream(self._side)
+            main.wait_stream(self._side2)
         if self._padded_model is not None:
             self._padded_model.scatter_grads()
+
+    def _wgrad_inputs(self, layer, t):
+        """(own rows, neighbor means, forward output, output gradient) of (layer, type) on the one-kernel
+        forward's tables."""
+        if layer == 0:
+            rows = self.h[0][t].shape[0]
+            return self.x_self[t], self.x_mean[0][t][:rows], self.h[0][t], self.g_h[0][t]
+        return self.h[0][t][:self.batch], self.x_mean[1][t][:self.batch], self.z[t], self.g_z[t]
+
+    def _grads_of(self, agg):
+        for p in agg.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        return agg.w_self.grad, agg.w_neigh.grad, None if agg.bias is None else agg.bias.grad
+
+    def _weight_grads(self, layer, t):
+        agg = self.model._aggs[layer][t]
+        x_self, x_mean, out, g_out = self._wgrad_inputs(layer, t)
+        g_ws, g_wn, g_b = self._grads_of(agg)
+        kernels.sage_project_bwd(x_self, x_mean, agg.w_self, agg.w_neigh, agg.activation, out, g_out,
+                                 need_x_self=False, need_x_mean=False, need_bias=g_b is not None,
+                                 g_w_self=g_ws, g_w_neigh=g_wn, g_bias=g_b, workspace=self.ws[layer][t])
+
+    def _wgrad_pair(self, layer):
+        problems = []
+        for t in _TYPES:
+            agg = self.model._aggs[layer][t]
+            x_self, x_mean, out, g_out = self._wgrad_inputs(layer, t)
+            g_ws, g_wn, g_b = self._grads_of(agg)
+            problems.append({'x_self': x_self, 'x_mean': x_mean, 'out': out, 'g_out': g_out, 'g_w_self': g_ws,
+                             'g_w_neigh': g_wn, 'g_bias': g_b, 'workspace': self.ws[layer][t]})
+        return kernels.WgradPairCall(problems, self.model._aggs[layer]['user'].activation)
 
     def backward(self, g_user, g_item):
         """Gradients of every aggregator weight from the embedding gradients; they

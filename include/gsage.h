@@ -212,6 +212,27 @@ int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_mean, int Fn
                         void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The weight and bias gradients of gs_sage_project_bwd for TWO projections of one
+ * shape at once -- the two node types of a layer, whose Aggregators have the same
+ * widths when both feature tables do (utils.py:72-89) -- with one weight-gradient
+ * launch and one reduction launch, so that a training step needs no second
+ * stream for them.  Each problem brings its own workspace of
+ * gs_sage_project_bwd_workspace(Fs, Fn, H, M) bytes.  out is the forward output
+ * (read for the relu mask, may be NULL for a linear layer); g_bias may be NULL.
+ */
+typedef struct gs_wgrad_problem {
+    const float *x_self, *x_mean;   /* [M, Fs], [M, Fn]  */
+    const float *out, *g_out;       /* [M, H]            */
+    float *g_W_self, *g_W_neigh;    /* [Fs, H/2], [Fn, H/2] */
+    float *g_bias;                  /* [H] or NULL       */
+    void *workspace;
+    size_t workspace_bytes;
+} gs_wgrad_problem;
+
+int gs_sage_project_wgrad_pair(const gs_wgrad_problem *a, const gs_wgrad_problem *b,
+                               int Fs, int Fn, int64_t M, int H, int act, void *stream);
+
+/*
  * out[m, :] = x[m, :] * rsqrt(max(sum(x[m, :]^2), 1e-12)) -- K.l2_normalize as
  * applied to the final embeddings (models.py:32,186-190) -- and its backward.
  */

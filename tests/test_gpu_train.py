@@ -437,3 +437,31 @@ def test_stage_batch_copies_inputs_and_rate_in_one_launch(cuda):
         kernels.stage_batch(seeds[:4], d_seeds, walks, d_walks, y, d_y)
     with pytest.raises(TypeError):
         kernels.stage_batch(seeds.long(), d_seeds, walks, d_walks, y, d_y)
+
+
+@pytest.mark.parametrize('m,fs,fn,h,act', [(1040, 64, 64, 32, 'relu'), (4096 * 26, 64, 64, 32, 'relu'), (48, 32, 32, 32, 'linear'),
+                                           (300, 24, 24, 32, 'relu'), (130, 128, 128, 64, 'linear')])
+def test_paired_weight_gradients_equal_two_single_calls(cuda, m, fs, fn, h, act):
+    """gs_sage_project_wgrad_pair (one launch for two problems; the (24, 24) case takes its
+    fallback) against gs_sage_project_bwd on each problem."""
+    from graphsage_amd import kernels
+    gen = torch.Generator(device=cuda).manual_seed(m + fs)
+    rnd = lambda *shape: torch.randn(shape, device=cuda, generator=gen)
+    ws_floats = kernels.project_bwd_workspace_floats(fs, fn, h, m)
+    problems, want = [], []
+    for k in range(2):
+        xs, xm, out, g = rnd(m, fs), rnd(m, fn), rnd(m, h), rnd(m, h)
+        with_bias = k == 0
+        want.append(kernels.sage_project_bwd(xs, xm, rnd(fs, h // 2), rnd(fn, h // 2), act, out, g,
+                                             need_x_self=False, need_x_mean=False, need_bias=with_bias)[:3])
+        problems.append({'x_self': xs, 'x_mean': xm, 'out': out if act == 'relu' or k else None, 'g_out': g,
+                         'g_w_self': torch.full((fs, h // 2), float('nan'), device=cuda),
+                         'g_w_neigh': torch.full((fn, h // 2), float('nan'), device=cuda),
+                         'g_bias': torch.full((h,), float('nan'), device=cuda) if with_bias else None,
+                         'workspace': torch.empty(max(ws_floats, 1), device=cuda)})
+    call = kernels.WgradPairCall(problems, act)
+    call.run()
+    for p, (g_ws, g_wn, g_b) in zip(problems, want):
+        assert torch.equal(p['g_w_self'], g_ws) and torch.equal(p['g_w_neigh'], g_wn)    # same kernels, same order of sums
+        if p['g_bias'] is not None:
+            assert torch.equal(p['g_bias'], g_b)
