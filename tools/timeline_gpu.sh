@@ -1,3 +1,6 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel trace of a short bench run, then the launches of the last
+# training step with their start offsets and durations -> gpurun_out/tl/timeline.txt
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/tl
