@@ -24,6 +24,8 @@ constexpr int kThreads = 1024;             // sixteen waves share one staged cop
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxH = 64;
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
 struct TailArgs {
     const float *z[2], *g_emb[2], *w_self[2], *w_neigh[2];
     float *g_z[2], *g_h1[2];
@@ -43,14 +45,25 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+template <int H1, int HH2>
 __global__ __launch_bounds__(kThreads)
 void sage2_tail_bwd_kernel(const TailArgs a) {
     extern __shared__ float smem[];
-    const int H1 = a.H1, H2 = a.H2, HH2 = H2 / 2;
-    const int wsz = HH2 * H1;
+    constexpr int H2 = 2 * HH2, wsz = HH2 * H1;
     float *wt = smem;                                             // [type][self, neigh][n][k]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *gz_s = smem + 4 * wsz + wave * kMaxH;                  // this wave's g_z row
+    const long long walks = 2 * a.n_pairs;
+    const long long w_first = (long long)blockIdx.x * kWaves + wave, w_step = (long long)gridDim.x * kWaves;
+
+    // the first walk's rows are requested before the weights, so that the two round trips overlap
+    float zc = 0.f, gc = 0.f;
+    if (w_first < walks && lane < H2) {
+        const int t = w_first >= a.n_pairs;
+        const long long p = w_first - (t ? a.n_pairs : 0);
+        zc = a.z[t][p * H2 + lane];
+        gc = a.g_emb[t][p * H2 + lane];
+    }
     for (int i = threadIdx.x; i < 4 * wsz; i += kThreads) {
         const int m = i / wsz, e = i - m * wsz;                   // e = k * HH2 + n: the weights are read in memory order
         const int k = e / HH2, n = e - k * HH2;
@@ -59,14 +72,15 @@ void sage2_tail_bwd_kernel(const TailArgs a) {
     }
     __syncthreads();
 
-    const int k = lane & (H1 - 1);                                // H1 is 32 or 64: lanes 32..63 repeat 0..31 when it is 32
+    const int k = lane & (H1 - 1);                                // H1 = 32: lanes 32..63 repeat 0..31
     const float inv_n0 = 1.f / (float)a.n0;
-    const long long walks = 2 * a.n_pairs;
-    for (long long w = (long long)blockIdx.x * kWaves + wave; w < walks; w += (long long)gridDim.x * kWaves) {
+    for (long long w = w_first; w < walks; w += w_step) {
         const int t = w >= a.n_pairs, o = 1 - t;
         const long long p = w - (t ? a.n_pairs : 0);
-        float zc = 0.f, gc = 0.f;
-        if (lane < H2) { zc = a.z[t][p * H2 + lane]; gc = a.g_emb[t][p * H2 + lane]; }
+        if (w != w_first) {
+            zc = gc = 0.f;
+            if (lane < H2) { zc = a.z[t][p * H2 + lane]; gc = a.g_emb[t][p * H2 + lane]; }
+        }
         float gz = gc;
         if (a.normalize) {
             const float ss = wave_sum(zc * zc), dot = wave_sum(zc * gc);
@@ -79,16 +93,22 @@ void sage2_tail_bwd_kernel(const TailArgs a) {
         wave_lds_fence();
         const float *ws = wt + (2 * t) * wsz, *wn = ws + wsz;
         float ds = 0.f, dn = 0.f;
+#pragma unroll
         for (int n = 0; n < HH2; ++n) {
             ds = fmaf(gz_s[n], ws[n * H1 + k], ds);
             dn = fmaf(gz_s[HH2 + n], wn[n * H1 + k], dn);
         }
         if (lane < H1) a.g_h1[t][p * H1 + lane] = ds;
-        // the n0 hop-1 heads of this walk: n0 * H1 consecutive floats, column = index mod H1 = this lane's k
-        const float v = dn * inv_n0;
-        float *dst = a.g_h1[o] + (a.n_pairs + p * a.n0) * H1;
-        const int span = a.n0 * H1;
-        for (int i = lane; i < span; i += 64) dst[i] = v;
+        // the n0 hop-1 heads of this walk: n0 * H1 consecutive floats repeating the H1 values dn / n0.  Stored
+        // 16 bytes per lane: the values go through the wave's LDS line so that a lane holds columns 4*lane .. +3
+        // (mod H1), which is what every one of its stores needs (256 is a multiple of H1)
+        wave_lds_fence();                                         // the dot products have read gz_s
+        if (lane < H1) gz_s[lane] = dn * inv_n0;
+        wave_lds_fence();
+        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(gz_s + ((4 * lane) & (H1 - 1)));
+        f32x4 *dst = reinterpret_cast<f32x4 *>(a.g_h1[o] + (a.n_pairs + p * a.n0) * H1);
+        const int span4 = a.n0 * (H1 / 4);
+        for (int i = lane; i < span4; i += 64) dst[i] = v4;
         wave_lds_fence();                                         // gz_s is rewritten by the next walk
     }
 }
@@ -103,13 +123,15 @@ extern "C" int gs_sage2_backward_tail(const float *z_user, const float *z_item,
                                       float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
                                       void *stream) {
     if (n_pairs < 0 || n0 < 1) return gs::fail(GS_EINVAL, "gs_sage2_backward_tail: n_pairs=%lld n0=%d", (long long)n_pairs, n0);
-    if ((H1 != 32 && H1 != 64) || H2 < 2 || H2 > kMaxH || (H2 & 1))
-        return gs::fail(GS_ELIMIT, "gs_sage2_backward_tail: H1=%d (32 or 64) H2=%d (even, at most %d)", H1, H2, kMaxH);
+    if ((H1 != 32 && H1 != 64) || (H2 != 32 && H2 != 64))
+        return gs::fail(GS_ELIMIT, "gs_sage2_backward_tail: H1=%d H2=%d (each 32 or 64: the widths of gs_sage2_forward)", H1, H2);
     if (act != GS_ACT_LINEAR && act != GS_ACT_RELU) return gs::fail(GS_EINVAL, "gs_sage2_backward_tail: unknown activation %d", act);
     if (n_pairs == 0) return GS_OK;
     if (!z_user || !z_item || !g_emb_user || !g_emb_item || !w1_self_user || !w1_neigh_user || !w1_self_item ||
         !w1_neigh_item || !g_z_user || !g_z_item || !g_h1_user || !g_h1_item)
         return gs::fail(GS_EINVAL, "gs_sage2_backward_tail: null pointer argument");
+    if ((reinterpret_cast<uintptr_t>(g_h1_user) | reinterpret_cast<uintptr_t>(g_h1_item)) & 15)
+        return gs::fail(GS_EINVAL, "gs_sage2_backward_tail: g_h1 tables must be 16-byte aligned");
     if (n_pairs > ((int64_t)1 << 40) / (1 + n0)) return gs::fail(GS_ELIMIT, "gs_sage2_backward_tail: n_pairs=%lld too large", (long long)n_pairs);
     TailArgs a{};
     a.z[0] = z_user; a.z[1] = z_item; a.g_emb[0] = g_emb_user; a.g_emb[1] = g_emb_item;
@@ -119,6 +141,10 @@ extern "C" int gs_sage2_backward_tail(const float *z_user, const float *z_item,
     int64_t blocks = (2 * n_pairs + kWaves - 1) / kWaves;
     if (blocks > 512) blocks = 512;
     const size_t lds = (size_t)(4 * (H2 / 2) * H1 + kWaves * kMaxH) * sizeof(float);        // at most 36 KB
-    hipLaunchKernelGGL(sage2_tail_bwd_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, a);
+    hipStream_t s = (hipStream_t)stream;
+    if (H1 == 32 && H2 == 32) hipLaunchKernelGGL((sage2_tail_bwd_kernel<32, 16>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a);
+    else if (H1 == 32) hipLaunchKernelGGL((sage2_tail_bwd_kernel<32, 32>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a);
+    else if (H2 == 32) hipLaunchKernelGGL((sage2_tail_bwd_kernel<64, 16>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL((sage2_tail_bwd_kernel<64, 32>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a);
     return gs::check_launch("gs_sage2_backward_tail");
 }

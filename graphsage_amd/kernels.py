@@ -412,7 +412,7 @@ def sage2_backward_tail(z, g_emb, w1_self, w1_neigh, n0, normalize, act, g_z, g_
 
 
 def sage2_backward_tail_supported(h1, h2):
-    return h1 in (32, 64) and h2 % 2 == 0 and 2 <= h2 <= 64
+    return h1 in (32, 64) and h2 in (32, 64)
 
 
 def fused_supported(fs, fn, h, max_child):

@@ -358,7 +358,8 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
  * gs_gather_mean_bwd of the layer-1 backward in one kernel; the layer-1 weight
  * gradients follow from g_z through gs_sage_project_bwd as usual.
  * w1_* are the layer-1 weights [H1, H2/2]; act is the layer-1 activation (z is
- * its output).  H1 is 32 or 64, H2 even and at most 64, else GS_ELIMIT.
+ * its output).  H1 and H2 are 32 or 64 (the widths of gs_sage2_forward), else
+ * GS_ELIMIT.
  */
 int gs_sage2_backward_tail(const float *z_user, const float *z_item,
                            const float *g_emb_user, const float *g_emb_item,
