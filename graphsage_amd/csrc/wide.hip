@@ -21,9 +21,14 @@
 //   consumer waves   four waves, each a 64x64 quarter of the tile: one
 //                    ds_read_b128 per 16x16 fragment feeds four
 //                    v_mfma_f32_16x16x4_f32.  They also fetch the 32 x 128 weight
-//                    slice of the next k slice before the multiply and put it into
-//                    the other LDS stage after it.  Bias, activation and 16-byte row
-//                    stores go through a wave-private LDS patch.
+//                    slice of the next k slice before the multiply (16-byte pieces of
+//                    the row-major weight, which is the order the lanes read them in:
+//                    MFMA j of a lane covers column 4r + j) and put it into the other
+//                    LDS stage after it.  Bias, activation and 16-byte row stores go
+//                    through a wave-private LDS patch (storing straight from the
+//                    accumulators, which hold four consecutive columns per row, was
+//                    measured 8 % slower: the next tile's MFMAs then wait for the
+//                    stores to have read their registers).
 //
 // All waves meet at one barrier per k slice.  Row ids of a tile (node id - table
 // offset, or "counts as zeros") are staged in LDS one tile ahead.  Neither the
@@ -41,8 +46,8 @@ using gs::kMaxSegs;
 
 constexpr int WM = 128, WN = 128, WK = 32;
 constexpr int W_TILE = WM * WK;                 // floats of one operand slice (A or B): 16 KB
-constexpr int kConsumerThreads = 256;           // four waves, 2 x 2 quarters of the tile
 constexpr int EP_LD = 68;                       // row stride of the epilogue patch (lane quarters 16 banks apart)
+constexpr int kConsumerThreads = 256;           // four waves, 2 x 2 quarters of the tile
 constexpr int kMaxChild = 32;
 
 // Hand-off through a wave-private LDS patch: a wave's LDS instructions execute in order, so only the
@@ -407,7 +412,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         const int colbase = d.side * HH + d.ct * WN + wave_n * 64;
         float bv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = a.bias ? a.bias[colbase + j * 16 + r] : 0.f;
+        for (int j = 0; j < 4; ++j) bv[j] = a.bias ? a.bias[colbase + 4 * r + j] : 0.f;   // MFMA j of a lane: column 4r + j
         float *__restrict__ outp = a.out + (sg.out_row0 + p0) * H + colbase;
         const uint32_t lane_off = (uint32_t)(q * H + r * 4);
 #pragma unroll
@@ -418,7 +423,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
                 for (int e = 0; e < 4; ++e) {
                     float val = acc[i][j][e] + bv[j];
                     if (a.act == GS_ACT_RELU) val = fmaxf(val, 0.f);
-                    E[(q * 4 + e) * EP_LD + j * 16 + r] = val;
+                    E[(q * 4 + e) * EP_LD + 4 * r + j] = val;
                     acc[i][j][e] = 0.f;
                 }
             wave_lds_fence();
@@ -438,45 +443,46 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
 #define WD_READ(S_, base_, half_, slot_)                                                            \
     {                                                                                               \
         const float *As_r = (base_) + ((half_) * 8 + wave_m * 4) * 256 + (slot_) * 4;               \
-        const float *Bs_r = (base_) + W_TILE + ((half_) * 8 + wave_n * 4) * 256 + lane * 4;         \
+        const float *Bs_r = (base_) + W_TILE + ((half_) * 8 + wave_n) * 256 + lane * 4;             \
         a##S_##0 = *reinterpret_cast<const f32x4 *>(As_r);                                          \
         b##S_##0 = *reinterpret_cast<const f32x4 *>(Bs_r);                                          \
         a##S_##1 = *reinterpret_cast<const f32x4 *>(As_r + 256);                                    \
-        b##S_##1 = *reinterpret_cast<const f32x4 *>(Bs_r + 256);                                    \
+        b##S_##1 = *reinterpret_cast<const f32x4 *>(Bs_r + 512);                                    \
         a##S_##2 = *reinterpret_cast<const f32x4 *>(As_r + 512);                                    \
-        b##S_##2 = *reinterpret_cast<const f32x4 *>(Bs_r + 512);                                    \
+        b##S_##2 = *reinterpret_cast<const f32x4 *>(Bs_r + 1024);                                   \
         a##S_##3 = *reinterpret_cast<const f32x4 *>(As_r + 768);                                    \
-        b##S_##3 = *reinterpret_cast<const f32x4 *>(Bs_r + 768);                                    \
+        b##S_##3 = *reinterpret_cast<const f32x4 *>(Bs_r + 1536);                                   \
     }
-#define WD_MFMA_ROW(i_, av_, S_, st_)                                                               \
-    acc[i_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], b##S_##0[st_], acc[i_][0], 0, 0, 0); \
-    acc[i_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], b##S_##1[st_], acc[i_][1], 0, 0, 0); \
-    acc[i_][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], b##S_##2[st_], acc[i_][2], 0, 0, 0); \
-    acc[i_][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], b##S_##3[st_], acc[i_][3], 0, 0, 0);
-#define WD_MFMA(S_)                                                                                 \
-    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                              \
-        WD_MFMA_ROW(0, a##S_##0, S_, s4) WD_MFMA_ROW(1, a##S_##1, S_, s4)                           \
-        WD_MFMA_ROW(2, a##S_##2, S_, s4) WD_MFMA_ROW(3, a##S_##3, S_, s4)                           \
-    }
+    // a##S##i: row tile i, element st = k step; b##S##st: k step st, element j = column tile (columns 4r + j)
+#define WD_MFMA_ROW(i_, av_, bv_, st_)                                                              \
+    acc[i_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[0], acc[i_][0], 0, 0, 0);       \
+    acc[i_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[1], acc[i_][1], 0, 0, 0);       \
+    acc[i_][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[2], acc[i_][2], 0, 0, 0);       \
+    acc[i_][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[3], acc[i_][3], 0, 0, 0);
+#define WD_MFMA_STEP(S_, st_)                                                                       \
+    WD_MFMA_ROW(0, a##S_##0, b##S_##st_, st_) WD_MFMA_ROW(1, a##S_##1, b##S_##st_, st_)             \
+    WD_MFMA_ROW(2, a##S_##2, b##S_##st_, st_) WD_MFMA_ROW(3, a##S_##3, b##S_##st_, st_)
+#define WD_MFMA(S_) WD_MFMA_STEP(S_, 0) WD_MFMA_STEP(S_, 1) WD_MFMA_STEP(S_, 2) WD_MFMA_STEP(S_, 3)
 
-    // weight slices: a thread gathers four consecutive k of one column (4 scalar loads, coalesced over
-    // columns; the four rows are uniform bases) for the slice after the one being multiplied, and writes
-    // them to the other LDS stage when the multiply is done
-    // (piece j of this thread: column (j*256 + tid) & 127, k quad (j*256 + tid) >> 7 = 2j + (tid >> 7); the
-    // LDS and weight offsets are recomputed where used rather than kept in registers)
-#define WD_B_COL (tid & 127)
-#define WD_B_KQ(j_) (2 * (j_) + (tid >> 7))
-#define WD_B_DST(j_) (W_TILE + ((WD_B_KQ(j_) >> 2) * 8 + (WD_B_COL >> 4)) * 256 + ((WD_B_KQ(j_) & 3) * 16 + (WD_B_COL & 15)) * 4)
-#define WD_B_OFF(j_) ((uint32_t)(WD_B_KQ(j_) * 4 * HH + WD_B_COL))
+    // weight slices, for the slice after the one being multiplied: a thread fetches four 16-byte pieces
+    // W[k][4c .. 4c+3] of the row-major weight (coalesced: 32 threads cover a 128-column row) and writes
+    // them to the other LDS stage when the multiply is done.  MFMA j of a 64-column group covers the
+    // columns n = 4r + j, so lane (r, q) needs exactly such a piece -- k = 16 half + 4q + st, c = 16 g + r --
+    // for its four MFMAs of k step st: the pieces go to LDS as they are, in the order the lanes read them.
+    // (piece j of this thread: k row (j*256 + tid) >> 5, column piece (j*256 + tid) & 31; the offsets are
+    // recomputed where used rather than kept in registers)
+#define WD_B_ROW(j_) (8 * (j_) + (tid >> 5))
+#define WD_B_C4 (tid & 31)
+#define WD_B_DST(j_) (W_TILE + ((((WD_B_ROW(j_) >> 4) * 4 + (WD_B_ROW(j_) & 3)) * 2 + (WD_B_C4 >> 4)) * 64 + ((WD_B_ROW(j_) >> 2) & 3) * 16 + (WD_B_C4 & 15)) * 4)
+#define WD_B_OFF(j_) ((uint32_t)(WD_B_ROW(j_) * HH + WD_B_C4 * 4))
     float4 bw0, bw1, bw2, bw3;
 #define WD_LOAD_B(cur_)                                                                             \
     {                                                                                               \
         const float *__restrict__ W0 = ((cur_).side ? a.W_neigh : a.W_self) + (long long)((cur_).ks * WK) * HH + (cur_).ct * WN; \
-        const float *__restrict__ W1 = W0 + HH, *__restrict__ W2 = W1 + HH, *__restrict__ W3 = W2 + HH; \
-        bw0 = make_float4(W0[WD_B_OFF(0)], W1[WD_B_OFF(0)], W2[WD_B_OFF(0)], W3[WD_B_OFF(0)]);                  \
-        bw1 = make_float4(W0[WD_B_OFF(1)], W1[WD_B_OFF(1)], W2[WD_B_OFF(1)], W3[WD_B_OFF(1)]);                  \
-        bw2 = make_float4(W0[WD_B_OFF(2)], W1[WD_B_OFF(2)], W2[WD_B_OFF(2)], W3[WD_B_OFF(2)]);                  \
-        bw3 = make_float4(W0[WD_B_OFF(3)], W1[WD_B_OFF(3)], W2[WD_B_OFF(3)], W3[WD_B_OFF(3)]);                  \
+        bw0 = *reinterpret_cast<const float4 *>(W0 + WD_B_OFF(0));                                  \
+        bw1 = *reinterpret_cast<const float4 *>(W0 + WD_B_OFF(1));                                  \
+        bw2 = *reinterpret_cast<const float4 *>(W0 + WD_B_OFF(2));                                  \
+        bw3 = *reinterpret_cast<const float4 *>(W0 + WD_B_OFF(3));                                  \
     }
 #define WD_STORE_B(stage_)                                                                          \
     {                                                                                               \
@@ -515,12 +521,13 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     if (pending) epilogue(done);
 #undef WD_READ
 #undef WD_LOAD_B
-#undef WD_B_COL
-#undef WD_B_KQ
+#undef WD_B_ROW
+#undef WD_B_C4
 #undef WD_B_DST
 #undef WD_B_OFF
 #undef WD_STORE_B
 #undef WD_MFMA_ROW
+#undef WD_MFMA_STEP
 #undef WD_MFMA
 }
 
@@ -563,6 +570,8 @@ int gs::sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream) {
     a.n_tiles = tiles;
     if (tiles == 0) return GS_OK;
     if (tiles >= (1ll << 24)) return gs::fail(GS_ELIMIT, "gs_sage_fused_fwd: more than 2^31 head nodes in one call");
+    if ((reinterpret_cast<uintptr_t>(a.W_self) | reinterpret_cast<uintptr_t>(a.W_neigh)) & 15)
+        return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: wide layers read the weights 16 bytes at a time; W_self / W_neigh must be 16-byte aligned");
     // tables below 4 GB are addressed with 32-bit byte offsets
     const bool big = (unsigned long long)a.n_rows_self * Fs * 4ull >= (1ull << 32) - 1024 ||
                      (unsigned long long)a.n_rows_neigh * Fn * 4ull >= (1ull << 32) - 1024;
