@@ -115,25 +115,15 @@ def test_projection_random_shapes_forward_and_backward(cuda, seed):
         assert np.abs(got - w).max() <= 3e-5 * max(1.0, np.abs(w).max()), name
 
 
-@pytest.mark.parametrize('seed', range(14))
-def test_forward_engine_random_models_against_the_oracle(cuda, seed):
-    """Whatever route the engine picks for the shape (one kernel, padded one kernel,
-    fused layers, general kernels; mean or max), embeddings equal the float64 oracle
-    applied to the ids the kernels sampled."""
+def _check_engine_against_oracle(cuda, rng, seed, fan, fu, fi, sizes, agg, nu, ni, b):
+    """Embeddings of the forward engine equal the float64 oracle applied to the ids the kernels sampled."""
     import graphsage_amd as ga
     from graphsage_amd.engine import SageForwardEngine
     from oracle import generator as ogen
     from oracle import model as omodel
-    rng = np.random.default_rng(300 + seed)
-    n_hops = int(rng.choice([1, 2, 2, 2, 3]))
-    fan = [int(rng.integers(1, [12, 6, 3][h] + 1)) for h in range(n_hops)]
-    fu, fi = int(rng.choice([8, 19, 24, 32, 64])), int(rng.choice([5, 18, 32, 64]))
-    sizes = [int(rng.choice([4, 16, 32, 64])) for _ in range(n_hops)]
-    agg = 'max' if seed % 5 == 4 else 'mean'
-    nu, ni, b = int(rng.integers(20, 300)), int(rng.integers(5, 60)), int(rng.integers(1, 40))
+    n_hops = len(fan)
     u = np.concatenate([rng.integers(0, nu, 1500), np.arange(nu)])
     it = np.concatenate([rng.integers(0, ni, 1500), np.arange(nu) % ni]) + nu
-    it[-nu:][np.arange(nu) % ni >= ni] = nu                       # (no-op guard: ids stay in range)
     for extra in range(ni):                                        # every item gets a neighbor
         u, it = np.append(u, extra % nu), np.append(it, nu + extra)
     e = np.stack([u, it])
@@ -167,7 +157,43 @@ def test_forward_engine_random_models_against_the_oracle(cuda, seed):
                for l, per in enumerate(model._aggs) for t, a in per.items()}
     want = omodel.forward(plan, weights, [torch.from_numpy(x) for x in xin], agg=agg)
     for k in range(2):
-        assert (out[k].cpu().double() - want[k]).abs().max().item() <= 1e-5, (n_hops, fan, fu, fi, sizes, agg)
+        assert (out[k].cpu().double() - want[k]).abs().max().item() <= 1e-5, (fan, fu, fi, sizes, agg)
+    return eng
+
+
+@pytest.mark.parametrize('seed', range(14))
+def test_forward_engine_random_models_against_the_oracle(cuda, seed):
+    """Whatever route the engine picks for the shape (one kernel, padded one kernel,
+    fused layers, general kernels; mean or max), embeddings equal the float64 oracle
+    applied to the ids the kernels sampled."""
+    rng = np.random.default_rng(300 + seed)
+    n_hops = int(rng.choice([1, 2, 2, 2, 3]))
+    fan = [int(rng.integers(1, [12, 6, 3][h] + 1)) for h in range(n_hops)]
+    fu, fi = int(rng.choice([8, 19, 24, 32, 64])), int(rng.choice([5, 18, 32, 64]))
+    sizes = [int(rng.choice([4, 16, 32, 64])) for _ in range(n_hops)]
+    agg = 'max' if seed % 5 == 4 else 'mean'
+    nu, ni, b = int(rng.integers(20, 300)), int(rng.integers(5, 60)), int(rng.integers(1, 40))
+    _check_engine_against_oracle(cuda, rng, seed, fan, fu, fi, sizes, agg, nu, ni, b)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_one_kernel_forward_over_its_supported_range(cuda, seed):
+    """The whole-walk kernel on every width combination it is built for, with fan-outs up to its
+    limits (64 first-hop samples, 4096 second-hop samples per walk) and odd batch sizes."""
+    rng = np.random.default_rng(500 + seed)
+    shapes = [(64, 64, 32, 32), (64, 64, 64, 64), (64, 64, 64, 32), (64, 64, 32, 64), (32, 32, 32, 32), (32, 32, 64, 64),
+              (128, 128, 32, 32), (128, 128, 64, 64), (64, 32, 32, 32), (32, 64, 32, 32)]
+    fu, fi, h1, h2 = shapes[seed]
+    n0 = int(rng.choice([1, 2, 7, 25, 40, 64]))
+    n1 = int(rng.choice([1, 3, 10, 33, 64]))
+    while n1 > 1 and not kernels.sage2_supported(fu, fi, h1, h2, n0, n1):     # LDS bounds the ids a wave keeps
+        n1 //= 2
+    assert kernels.sage2_supported(fu, fi, h1, h2, n0, n1), (fu, fi, h1, h2, n0, n1)
+    nu, ni, b = int(rng.integers(20, 300)), int(rng.integers(5, 60)), int(rng.choice([1, 3, 17, 64]))
+    if n0 * n1 > 1000:
+        b = min(b, 5)                                              # keeps the float64 restatement small
+    eng = _check_engine_against_oracle(cuda, rng, seed, [n0, n1], fu, fi, [h1, h2], 'mean', nu, ni, b)
+    assert eng.walk_kernel, "this shape is expected to take the one-kernel route"
 
 
 @pytest.mark.parametrize('seed', range(16))
