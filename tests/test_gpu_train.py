@@ -101,7 +101,12 @@ def test_short_run_learns(cuda):
                                         ([3, 2], [32, 32], 128), ([10, 5], [64, 32], 32), ([7], [32], 64),
                                         ([2, 2, 2, 2], [32, 32, 32, 32], 32), ([12, 1], [32, 64], 64),
                                         ([8, 4], [32, 32], (24, 19)), ([5, 3, 2], [32, 64, 32], (28, 18)),
-                                        ([5, 3, 2], [256, 256, 256], 64), ([4, 3], [256, 256], (128, 96))])   # wide layers
+                                        ([5, 3, 2], [256, 256, 256], 64), ([4, 3], [256, 256], (128, 96)),   # wide layers
+                                        # two hops over the other widths of the one-kernel forward; unequal feature
+                                        # widths take the backward route without paired weight gradients
+                                        ([6, 3], [64, 64], 64), ([6, 3], [64, 64], 32),
+                                        ([5, 2], [32, 32], (64, 32)), ([5, 2], [32, 32], (32, 64)),
+                                        ([5, 2], [64, 32], 64), ([5, 2], [32, 64], 64)])
 def test_plan_engine_step_equals_autograd_step(cuda, ns, sizes, f):
     """The static training plan (fused forward with saved activations + kernel
     backward) produces the same loss, gradients and updated weights as the
