@@ -39,10 +39,15 @@ class SageTrainEngine(SageForwardEngine):
         if self.agg_max:
             raise kernels._lib.GsageError("the training plan covers the mean aggregator; agg_option='max' trains "
                                           "through graphsage_amd.train.Trainer(engine='autograd')")
-        if not all(self.fused_layers):
+        f = graph.node_feature_sizes
+        # two hops: sampling, both layers and everything the backward pass reads in ONE kernel
+        self.walk_train = bool(self.n_hops == 2 and kernels.sage2_supported(
+            f['user'], f['item'], self.model.dims[1]['user'], self.model.dims[2]['user'], *self.fanouts))
+        if not all(self.fused_layers) and not self.walk_train:
             raise kernels._lib.GsageError(
-                "the training plan needs a fused layer kernel for every layer (widths 32/64/128 with half-widths 16 "
-                "or 32, or multiples of 32 with half-widths that are multiples of 128); use "
+                "the training plan needs a two-hop shape of the one-kernel forward or a fused layer kernel for every "
+                "layer (widths 32/64/128 with half-widths 16 or 32, or multiples of 32 with half-widths that are "
+                "multiples of 128); use "
                 "graphsage_amd.train.Trainer(engine='autograd') for other shapes")
         m = self.model
         dev = self.indptr.device
@@ -59,10 +64,6 @@ class SageTrainEngine(SageForwardEngine):
             dtype=torch.float32, device=dev) for t in _TYPES} for layer in range(self.n_hops)]
         self._train_calls = {}
         self._side = None                                       # second stream of the backward pass
-        # two hops: sampling, both layers and everything the backward pass reads in ONE kernel
-        f = graph.node_feature_sizes
-        self.walk_train = bool(self.n_hops == 2 and kernels.sage2_supported(
-            f['user'], f['item'], m.dims[1]['user'], m.dims[2]['user'], *self.fanouts))
         self._walk_train_call = None
         # ... and then the top of the backward pass in one kernel as well (see _backward_walks)
         self.tail_kernel = self.walk_train and kernels.sage2_backward_tail_supported(m.dims[1]['user'], m.dims[2]['user'])

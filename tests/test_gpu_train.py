@@ -104,7 +104,7 @@ def test_short_run_learns(cuda):
                                         ([5, 3, 2], [256, 256, 256], 64), ([4, 3], [256, 256], (128, 96)),   # wide layers
                                         # two hops over the other widths of the one-kernel forward; unequal feature
                                         # widths take the backward route without paired weight gradients
-                                        ([6, 3], [64, 64], 64), ([6, 3], [64, 64], 32),
+                                        ([6, 3], [64, 64], 64), ([6, 3], [64, 64], 32), ([4, 2], [64, 64], 128),
                                         ([5, 2], [32, 32], (64, 32)), ([5, 2], [32, 32], (32, 64)),
                                         ([5, 2], [64, 32], 64), ([5, 2], [32, 64], 64)])
 def test_plan_engine_step_equals_autograd_step(cuda, ns, sizes, f):
