@@ -54,7 +54,8 @@ def test_one_step_matches_oracle(cuda):
     want_loss.backward()
 
     loss, pred = tr.step(batch, t)
-    assert abs(float(loss) - float(want_loss)) < 1e-5 * max(1.0, float(want_loss))
+    want_loss = float(want_loss.detach())
+    assert abs(float(loss.detach()) - want_loss) < 1e-5 * max(1.0, want_loss)
     ref_params = [weights[(l, ty)][n] for l, aggs in enumerate(model._aggs) for ty, a in aggs.items()
                   for n in ('w_self', 'w_neigh', 'bias')] + [kernel, hbias]
     assert len(ref_params) == len(tr.params)
@@ -150,7 +151,7 @@ def test_plan_engine_step_equals_autograd_step(cuda, ns, sizes, f):
         before = [p.detach().clone() for p in tr.params]
         loss_g, _ = tr.step_graph(seeds, t, walk_ids, rng_seed=77)
         assert np.isfinite(float(loss_g)) and float(loss_g) < l1 + 1e-3
-        assert any(float((a - c).abs().max()) > 0 for a, c in zip(before, tr.params))
+        assert any(float((a - c.detach()).abs().max()) > 0 for a, c in zip(before, tr.params))
 
 
 def test_link_head_kernel_and_adam_kernel(cuda):
