@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/tl
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 20 > $OUT/trace.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 20 "$@" > $OUT/trace.log 2>&1 || exit 1
 python3 - <<PY
 import csv,glob
 f=glob.glob('$OUT/trace/*/*kernel_trace.csv')[0]
