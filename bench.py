@@ -6,9 +6,12 @@
 A step = one batch of B seed edges through the hot path with every input already
 in HBM: sampler kernel (Philox draws) -> feature gathers and fused gather-mean ->
 per-type MFMA projections -> second layer -> l2-normalised user/item embeddings.
-N > 1 (launched by torch.distributed.run): the graph and features are replicated,
-rank r takes its own batches of seed edges, the forward pass needs no collective,
-and the reported value is the sum over ranks divided by the slowest rank's time.
+N > 1: the graph and features are replicated, rank r takes its own batches of seed
+edges, the forward pass needs no collective, and the reported value is the sum over
+ranks divided by the slowest rank's time.  The ranks come either from a launcher
+around this script (torch.distributed.run sets WORLD_SIZE) or, when there is none,
+from this script itself: ``python bench.py --gpus N`` starts N ranks and relays rank
+0's line.  A rank count other than --gpus ends the run with a non-zero status.
 
 Environment switches for comparisons: BENCH_UNFUSED=1 runs the forward pass on the
 general kernels (sample, gather-mean, projection) instead of the fused ones;
@@ -64,7 +67,59 @@ def parse():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL)')
     ap.add_argument('--train-timeout', type=int, default=300, help='seconds before the train timing is abandoned')
     ap.add_argument('--train-steps', type=int, default=20, help='steps of the secondary fwd+bwd+all-reduce+Adam timing (0: skip)')
+    ap.add_argument('--dry-launch', action='store_true',
+                    help='only start the ranks, rendezvous and count them (no GPU work); checks the launcher')
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher around it: start the N ranks
+    here, one per GPU, as children of ``torch.distributed.run`` (this process has
+    not touched the GPU yet and never will), pass their output through, and fail
+    if the job fails or rank 0 never reports N ranks."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    seen = None
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith('{'):
+            try:
+                seen = json.loads(line).get('ranks_seen')
+            except ValueError:
+                pass
+    rc = proc.wait()
+    if rc == 0 and seen != args.gpus:
+        print("bench.py: asked for %d ranks, the job reported %s" % (args.gpus, seen), file=sys.stderr)
+        rc = 4
+    sys.exit(rc)
+
+
+def dry_launch(args, rank, world):
+    """Rendezvous only: every rank adds 1 to a counter over the chosen backend."""
+    import torch
+    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        dist.init_process_group(args.backend)
+        t = torch.ones(1, dtype=torch.int64)
+        if args.backend == 'nccl':
+            t = t.cuda(int(os.environ.get('LOCAL_RANK', 0)) % max(torch.cuda.device_count(), 1))
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": seen, "backend": args.backend}), flush=True)
+    sys.exit(0 if seen == args.gpus else 4)
 
 
 def cpu_baseline(graph, cfg, heads_u, heads_i, model, n_batches, batch=100):
@@ -180,7 +235,7 @@ def autograd_train_step(args, ga, gen, model, heads_u, heads_i, b, rank, world, 
         return {"skipped": "%s; autograd path: %s" % (why, str(ex)[:160])}
 
 
-def result_line(args, cfg, engine, world, b, fwd, train, cpu):
+def result_line(args, cfg, engine, world, b, fwd, train, cpu, ranks_seen=1):
     """The one JSON line rank 0 prints."""
     elapsed = fwd["elapsed"]
     value = args.steps * b * world / elapsed
@@ -192,7 +247,9 @@ def result_line(args, cfg, engine, world, b, fwd, train, cpu):
     out = {
         "metric": "seed edges/sec (2-hop sample+aggregate fwd)" if len(cfg['fan']) == 2
                   else "seed edges/sec (%d-hop sample+aggregate fwd)" % len(cfg['fan']),
-        "value": value, "unit": "seed edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "seed edges/s", "n_gpus": world, "ranks_seen": ranks_seen,
+        "backend": (args.backend + (" (RCCL)" if args.backend == 'nccl' else "")) if world > 1 else None,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, cfg['desc']), "batch_per_gpu": b,
@@ -218,14 +275,22 @@ def result_line(args, cfg, engine, world, b, fwd, train, cpu):
 
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        launch_ranks(args)                                   # does not return
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        # never report one GPU's number under another count
+        print("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(4)
+    if args.dry_launch:
+        dry_launch(args, rank, world)
     # a rank that stops making progress must not leave the job hanging: dump where it is and exit
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get('BENCH_WATCHDOG_S', '900')), exit=True)
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -236,8 +301,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
     sync_dev = device if args.backend == 'nccl' else torch.device('cpu')
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    ranks_seen = dist.get_world_size() if world > 1 else 1
 
     import graphsage_amd as ga
     from graphsage_amd import synthetic
@@ -301,11 +365,13 @@ def main():
     import threading
 
     def give_up():
+        # the forward number is still reported, but a stalled step is a failure of the run
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
         if rank == 0:
             print(json.dumps(result_line(args, cfg, engine, world, b, fwd,
                                          {"skipped": "training step did not finish within %d s" % args.train_timeout},
-                                         None)), flush=True)
-        os._exit(0)
+                                         None, ranks_seen)), flush=True)
+        os._exit(3)
 
     guard = threading.Timer(args.train_timeout, give_up)
     guard.daemon = True
@@ -360,7 +426,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(graph, cfg, heads_u, heads_i, model, args.cpu_batches)
-        print(json.dumps(result_line(args, cfg, engine, world, b, fwd, train, cpu)), flush=True)
+        print(json.dumps(result_line(args, cfg, engine, world, b, fwd, train, cpu, ranks_seen)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

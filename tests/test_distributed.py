@@ -91,3 +91,29 @@ def test_adam_matches_keras_update_rule():
         x = x - 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-7)
         opt.step()
         np.testing.assert_allclose(p.detach().numpy(), x, rtol=1e-5)
+
+
+def _run_bench(argv, env_extra=None, drop=('WORLD_SIZE', 'RANK', 'LOCAL_RANK')):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + argv, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_starts_its_own_ranks():
+    """``bench.py --gpus 2`` with no launcher around it starts two ranks that meet
+    (gloo here, no GPU work) and rank 0's line says how many it saw."""
+    import json
+    res = _run_bench(['--gpus', '2', '--backend', 'gloo', '--dry-launch'])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and lines[0]['ranks_seen'] == 2 and lines[0]['n_gpus'] == 2
+
+
+def test_bench_refuses_a_rank_count_other_than_asked():
+    res = _run_bench(['--gpus', '2', '--backend', 'gloo', '--dry-launch'],
+                     env_extra={'WORLD_SIZE': '1', 'RANK': '0'}, drop=())
+    assert res.returncode != 0 and 'ranks' in res.stderr
