@@ -109,10 +109,11 @@ void link_head_reduce_kernel(const float *__restrict__ slab, int n_blocks, int C
 
 __global__ __launch_bounds__(kThreads)
 void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
-                 int64_t n, float lr_arg, const float *__restrict__ lr_dev, float b1, float b2, float eps) {
+                 int64_t n, float lr_arg, const float *__restrict__ lr_dev, float b1, float b2, float eps,
+                 float grad_scale) {
     const float lr_t = lr_dev ? lr_dev[0] : lr_arg;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-        const float gi = g[i];
+        const float gi = g[i] * grad_scale;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi;
@@ -184,14 +185,15 @@ extern "C" int gs_link_head_mse_fwd_bwd(const float *emb_user, const float *emb_
 }
 
 extern "C" int gs_adam_step(float *params, const float *grads, float *m, float *v, int64_t n,
-                            float lr_t, const float *lr_t_device, float beta1, float beta2, float eps, void *stream) {
+                            float lr_t, const float *lr_t_device, float beta1, float beta2, float eps,
+                            float grad_scale, void *stream) {
     if (n < 0) return gs::fail(GS_EINVAL, "gs_adam_step: n=%lld", (long long)n);
     if (n == 0) return GS_OK;
     if (!params || !grads || !m || !v) return gs::fail(GS_EINVAL, "gs_adam_step: null pointer argument");
     int64_t blocks = (n + kThreads - 1) / kThreads;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, params, grads, m, v, n,
-                       lr_t, lr_t_device, beta1, beta2, eps);
+                       lr_t, lr_t_device, beta1, beta2, eps, grad_scale);
     return gs::check_launch("gs_adam_step");
 }
 

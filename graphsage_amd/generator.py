@@ -112,6 +112,7 @@ class LinkSequence:
         self.rank, self.world_size = rank, world_size
         self._rs, _ = random_state(seed)
         self._indexed = getattr(sample_function, '_accepts_link_index', False)
+        self.salt = 0                  # set by the generator: distinguishes the draws of its sequences
         self.epoch = -1
         self.on_epoch_end()
 
@@ -127,7 +128,8 @@ class LinkSequence:
         head_ids = [self.ids[ii] for ii in batch_indices]
         batch_targets = self.targets[batch_indices]
         if self._indexed:
-            batch_feats = self._sample_features(head_ids, batch_num, link_index=batch_indices, epoch=self.epoch)
+            batch_feats = self._sample_features(head_ids, batch_num, link_index=batch_indices, epoch=self.epoch,
+                                                salt=self.salt)
         else:
             batch_feats = self._sample_features(head_ids, batch_num)
         return batch_feats, batch_targets
@@ -143,7 +145,7 @@ class LinkSequence:
             raise IndexError("Mapper: batch_num larger than length of data")
         batch_indices = self.indices[start_idx:start_idx + self.batch_size]
         head_ids = [self.ids[ii] for ii in batch_indices]
-        seeds, walk_ids, key = self._sample_features.roots(head_ids, batch_indices, self.epoch)
+        seeds, walk_ids, key = self._sample_features.roots(head_ids, batch_indices, self.epoch, self.salt)
         return seeds, walk_ids, key, (None if self.targets is None else self.targets[batch_indices])
 
     def epoch_on_device(self):
@@ -157,7 +159,8 @@ class LinkSequence:
             return self._staged
         n_full = self.data_size // self.batch_size
         idx = np.asarray(self.indices[:n_full * self.batch_size], dtype=np.int64)
-        self._staged = self._sample_features.stage(self.ids, idx, n_full, self.batch_size, self.targets, self.epoch)
+        self._staged = self._sample_features.stage(self.ids, idx, n_full, self.batch_size, self.targets, self.epoch,
+                                                   self.salt)
         self._staged_epoch = self.epoch
         return self._staged
 
@@ -238,14 +241,14 @@ class _IndexedSampler:
     def __init__(self, gen):
         self._gen = gen
 
-    def __call__(self, head_links, batch_num, link_index=None, epoch=0):
-        return self._gen._sample(head_links, link_index, epoch)
+    def __call__(self, head_links, batch_num, link_index=None, epoch=0, salt=0):
+        return self._gen._sample(head_links, link_index, epoch, salt)
 
-    def roots(self, head_links, link_index, epoch):
+    def roots(self, head_links, link_index, epoch, salt=0):
         roots, walk_ids, _ = self._gen._roots(head_links, link_index)
-        return roots, walk_ids, _mix64(self._gen._base_seed(), epoch)
+        return roots, walk_ids, self._gen.sampling_key(epoch, salt)
 
-    def stage(self, ids, idx, n_full, b, targets, epoch):
+    def stage(self, ids, idx, n_full, b, targets, epoch, salt=0):
         import torch
         from ._lib import require_gpu
         dev = require_gpu()
@@ -266,7 +269,7 @@ class _IndexedSampler:
         walk = np.concatenate([2 * li, 2 * li + 1], axis=1)
         out = {'roots': torch.from_numpy(np.ascontiguousarray(roots)).to(dev),
                'walk_ids': torch.from_numpy(np.ascontiguousarray(walk)).to(dev),
-               'targets': None, 'key': _mix64(gen._base_seed(), epoch), 'n_batches': n_full}
+               'targets': None, 'key': gen.sampling_key(epoch, salt), 'n_batches': n_full}
         if targets is not None:
             out['targets'] = torch.from_numpy(np.asarray(targets, dtype=np.float32)[idx].reshape(n_full, b)).to(dev)
         return out
@@ -286,6 +289,7 @@ class GraphSAGEGenerator(BatchedLinkGenerator):
         self._slot_types = [_TYPES[(s + h) % 2] for h in range(n_hops + 1) for s in range(2)]
         self._sampling_schema = self._schema(num_samples)
         self._indexed = _IndexedSampler(self)
+        self._n_flows = 0
 
     @staticmethod
     def _schema(num_samples):
@@ -316,7 +320,17 @@ class GraphSAGEGenerator(BatchedLinkGenerator):
         if seq is not None:
             seq._sample_features = self._indexed
             seq._indexed = True
+            # The reference draws all its sequences' samples from one global stream, so link i of the
+            # training sequence and link i of the validation sequence get unrelated neighborhoods.
+            # Here draws are addressed by link position; the sequence's ordinal goes into the key so
+            # that the same holds.  Ranks of a data-parallel job call flow() in the same order.
+            seq.salt = self._n_flows
+            self._n_flows += 1
         return seq
+
+    def sampling_key(self, epoch, salt=0):
+        """Philox key of one epoch of one sequence."""
+        return _mix64(_mix64(self._base_seed(), salt), epoch)
 
     def sample_features(self, head_links, batch_num):
         """Reference signature (``generator.py:281``): walk ids continue from the
@@ -345,11 +359,11 @@ class GraphSAGEGenerator(BatchedLinkGenerator):
             walk_ids = torch.from_numpy(np.concatenate([2 * li, 2 * li + 1])).to(dev)
         return roots, walk_ids, b
 
-    def _sample(self, head_links, link_index, epoch):
+    def _sample(self, head_links, link_index, epoch, salt=0):
         roots, walk_ids, b = self._roots(head_links, link_index)
-        if walk_ids is not None:
-            self.sampler.seed = _mix64(self._base_seed(), epoch)
-        hops = self.sampler.sample_device(roots, walk_ids=walk_ids)
+        # keyed sequences bring their own key; the walker's seed (running-counter calls) is not touched
+        key = self.sampling_key(epoch, salt) if walk_ids is not None else None
+        hops = self.sampler.sample_device(roots, walk_ids=walk_ids, rng_seed=key)
         slot_ids = [roots[:b].reshape(b, 1), roots[b:].reshape(b, 1)]
         for hop in hops:
             slot_ids.append(hop[:b])

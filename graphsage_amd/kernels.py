@@ -52,6 +52,21 @@ class LaunchTimer:
             pass
 
 
+# Prepared calls keep raw device addresses of the weights.  Code that moves parameters into other
+# storage (FlatGradBucket re-points every parameter into one flat buffer) announces it here; a
+# prepared call compares one integer per run and re-reads the addresses when it has changed.
+_storage_epoch = 0
+
+
+def parameters_moved():
+    global _storage_epoch
+    _storage_epoch += 1
+
+
+def storage_epoch():
+    return _storage_epoch
+
+
 def hop_sizes(fanouts):
     out, p = [], 1
     for n in fanouts:
@@ -383,8 +398,11 @@ class WgradPairCall:
                                                    ptr(p['workspace']), p['workspace'].numel() * 4))
         self._args = (fs, fn, m, h, ACT[act])
         self._lib = lib
+        self.epoch = _storage_epoch            # the gradient views it writes belong to this parameter layout
 
     def run(self):
+        if self.epoch != _storage_epoch:
+            raise _lib.GsageError("parameters were moved to other storage after this call was prepared; prepare it again")
         check(self._lib.gs_sage_project_wgrad_pair(ctypes.byref(self._structs[0]), ctypes.byref(self._structs[1]),
                                                    *self._args, stream_handle()), 'gs_sage_project_wgrad_pair')
 
@@ -472,10 +490,16 @@ class FusedLayerCall:
         self._arr = arr
         self._live_heads = {}
         self._keep += [feat_self, feat_neigh, w_self, w_neigh, bias, out, save_self, save_mean]
-        self._args = (ptr(feat_self), feat_self.shape[0], fs, int(off_self), ptr(feat_neigh), feat_neigh.shape[0],
-                      fn, int(off_neigh), arr, len(segments), ptr(w_self), ptr(w_neigh), ptr(bias), 2 * hh,
-                      ACT[act], int(bool(normalize)), ptr(out), ptr(save_self), ptr(save_mean))
+        self._weights = (w_self, w_neigh, bias)
+        self._head = (ptr(feat_self), feat_self.shape[0], fs, int(off_self), ptr(feat_neigh), feat_neigh.shape[0],
+                      fn, int(off_neigh), arr, len(segments))
+        self._tail = (2 * hh, ACT[act], int(bool(normalize)), ptr(out), ptr(save_self), ptr(save_mean))
+        self._read_weight_addresses()
         self.out = out
+
+    def _read_weight_addresses(self):
+        self._args = self._head + tuple(ptr(w) for w in self._weights) + self._tail
+        self._epoch = _storage_epoch
 
     def set_head_ids(self, seg, head_ids):
         """Points segment ``seg`` at another head-id array of the same length."""
@@ -486,6 +510,8 @@ class FusedLayerCall:
         self._live_heads[seg] = head_ids
 
     def run(self):
+        if self._epoch != _storage_epoch:
+            self._read_weight_addresses()
         check(self._lib.gs_sage_fused_fwd(*self._args, stream_handle()), 'gs_sage_fused_fwd')
         return self.out
 
@@ -528,6 +554,8 @@ class Sage2Call:
         if indptr.numel() != nu + ni + 1:
             raise ValueError("indptr must have n_users + n_items + 1 entries")
         self._w = []
+        self._weights = weights
+        self._epoch = _storage_epoch
         dims = {}
         for layer in (0, 1):
             for t in ('user', 'item'):
@@ -580,7 +608,18 @@ class Sage2Call:
                          ptr(self.hop2))
         self._n0, self._n1 = n0, n1
 
+    def _read_weight_addresses(self):
+        i = 0
+        for layer in (0, 1):
+            for t in ('user', 'item'):
+                w_self, w_neigh, bias = self._weights[(layer, t)]
+                self._w[i].w_self, self._w[i].w_neigh, self._w[i].bias = ptr(w_self), ptr(w_neigh), ptr(bias)
+                i += 1
+        self._epoch = _storage_epoch
+
     def run(self, seeds, err_flag, rng_seed=0, walk_id_base=0, walk_ids=None, replay=None):
+        if self._epoch != _storage_epoch:
+            self._read_weight_addresses()
         _dev(seeds, torch.int32, 'seeds', 1)
         _dev(err_flag, torch.int32, 'err_flag', 1)
         if seeds.numel() != 2 * self.n_pairs:
@@ -637,8 +676,11 @@ class LinkHeadStep:
         self.ws = new(max(lib.gs_link_head_workspace(self.b, self.e) // 4, 1))
         self._lib = lib
         self._keep = (kernel, bias, g_kernel, g_bias)
+        self.epoch = _storage_epoch
 
     def run(self, emb_user, emb_item, targets):
+        if self.epoch != _storage_epoch:
+            raise _lib.GsageError("parameters were moved to other storage after this call was prepared; prepare it again")
         kernel, bias, g_kernel, g_bias = self._keep
         for name, t, shape in (('emb_user', emb_user, (self.b, self.e)), ('emb_item', emb_item, (self.b, self.e))):
             _dev(t, torch.float32, name, 2)
@@ -654,8 +696,9 @@ class LinkHeadStep:
         return self.loss, self.pred
 
 
-def adam_step(params_flat, grads_flat, m, v, lr_t, beta1, beta2, eps, lr_t_device=None):
-    """lr_t_device: optional 1-element GPU tensor holding the rate (read by the kernel)."""
+def adam_step(params_flat, grads_flat, m, v, lr_t, beta1, beta2, eps, lr_t_device=None, grad_scale=1.0):
+    """lr_t_device: optional 1-element GPU tensor holding the rate (read by the kernel);
+    grad_scale multiplies every gradient as it is read (1 / world after a summing all-reduce)."""
     lib = load()
     if lr_t_device is not None:
         _dev(lr_t_device, torch.float32, 'lr_t_device')
@@ -664,7 +707,8 @@ def adam_step(params_flat, grads_flat, m, v, lr_t, beta1, beta2, eps, lr_t_devic
         if t.numel() != params_flat.numel():
             raise ValueError("flat optimizer buffers differ in length")
     check(lib.gs_adam_step(ptr(params_flat), ptr(grads_flat), ptr(m), ptr(v), params_flat.numel(), float(lr_t),
-                           ptr(lr_t_device), float(beta1), float(beta2), float(eps), stream_handle()), 'gs_adam_step')
+                           ptr(lr_t_device), float(beta1), float(beta2), float(eps), float(grad_scale), stream_handle()),
+          'gs_adam_step')
 
 
 def stage_batch(seeds, seeds_dst, walk_ids, walk_ids_dst, targets, targets_dst, lr_t=0.0, lr_dst=None):

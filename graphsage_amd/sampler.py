@@ -44,9 +44,11 @@ class BreadthFirstWalker:
         self._replay = None if tape is None else np.ascontiguousarray(tape, dtype=np.uint32)
 
     # -- device-side entry: everything stays on the GPU ---------------------
-    def sample_device(self, seeds, walk_ids=None, check=True):
+    def sample_device(self, seeds, walk_ids=None, check=True, rng_seed=None):
         """seeds: int32 GPU tensor of roots.  Returns the per-hop int32 tensors
-        ``[len(seeds), n0*...*nh]`` in breadth-first order."""
+        ``[len(seeds), n0*...*nh]`` in breadth-first order.  ``rng_seed`` keys
+        this call's draws instead of the walker's own seed (which is left as it
+        is)."""
         import torch
         dev = self.graph.device_tensors()
         replay = None
@@ -54,7 +56,8 @@ class BreadthFirstWalker:
             replay = torch.from_numpy(self._replay.view(np.int32)).to(seeds.device)
             self._replay = None
         hops, err = kernels.sample(dev['indptr'], dev['indices'], seeds, self.num_of_walks,
-                                   rng_seed=self.seed, walk_id_base=self.next_walk_id,
+                                   rng_seed=self.seed if rng_seed is None else int(rng_seed),
+                                   walk_id_base=self.next_walk_id,
                                    walk_ids=walk_ids, replay=replay)
         if walk_ids is None:
             self.next_walk_id += int(seeds.numel())

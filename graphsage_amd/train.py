@@ -71,6 +71,9 @@ class FlatGradBucket:
             p.data = self.flat_params[off:off + n].view_as(p)
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
+        # prepared kernel calls cache the weights' device addresses: tell them the weights moved
+        from . import kernels
+        kernels.parameters_moved()
 
     def zero(self):
         self.flat.zero_()
@@ -92,6 +95,24 @@ class FlatGradBucket:
                 torch.cuda.synchronize()
             self.flat.div_(world)
         return self.flat
+
+    def all_reduce_sum(self, group=None):
+        """Sum over ranks, left undivided; returns the factor (1 / world) the
+        optimizer applies to the gradients as it reads them, which saves the
+        division pass.  1.0 for a single process."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1.0
+        world = dist.get_world_size(group)
+        if world <= 1:
+            return 1.0
+        fence = self.flat.is_cuda and dist.get_backend(group) == 'gloo'
+        if fence:
+            torch.cuda.synchronize()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if fence:
+            torch.cuda.synchronize()
+        return 1.0 / world
 
 
 class Adam:
@@ -116,19 +137,22 @@ class Adam:
         return self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
 
     @torch.no_grad()
-    def step(self, launch=True):
+    def step(self, launch=True, grad_scale=1.0):
         """launch=False only refreshes the device-side rate (the update kernel
-        itself is then part of a replayed HIP graph)."""
+        itself is then part of a replayed HIP graph).  grad_scale multiplies the
+        gradients as they are read (1 / world after a summing all-reduce)."""
         lr_t = self.next_rate()
         if self.p_flat is not None and self.g.is_cuda:
             from . import kernels
-            if self.lr_dev is not None:                  # graph replay: the rate travels through memory
+            if not launch:                               # graph replay: the rate travels through memory
                 self.lr_dev.fill_(lr_t)
-                if not launch:
-                    return
+                return
+            # launched here: the rate goes by value, one launch and no fill
             kernels.adam_step(self.p_flat, self.g, self.m, self.v, lr_t, self.b1, self.b2, self.eps,
-                              lr_t_device=self.lr_dev)
+                              grad_scale=grad_scale)
             return
+        if grad_scale != 1.0:
+            self.g.mul_(grad_scale)
         self.m.mul_(self.b1).add_(self.g, alpha=1 - self.b1)
         self.v.mul_(self.b2).addcmul_(self.g, self.g, value=1 - self.b2)
         upd = self.m / (self.v.sqrt() + self.eps)
@@ -158,6 +182,7 @@ class Trainer:
         self._graph_obj, self._batch_size = graph, batch_size
         self.group = group
         self.engine = None
+        self.engine_fallback_reason = None                   # why engine='auto' took the autograd route, if it did
         if not isinstance(self.head, LinkHead):
             # heads other than concat -> Dense(1, sigmoid) are torch modules: the model trains through autograd
             if engine == 'plan':
@@ -165,11 +190,13 @@ class Trainer:
             engine = 'autograd'
         if engine in ('auto', 'plan') and graph is not None and batch_size is not None:
             from .train_engine import SageTrainEngine
+            from ._lib import GsageError
             try:
                 self.engine = SageTrainEngine(graph, self.model, batch_size)
-            except Exception:
+            except (GsageError, ValueError) as ex:          # a shape the plan does not cover; anything else is a bug
                 if engine == 'plan':
                     raise
+                self.engine_fallback_reason = str(ex)
         elif engine == 'plan':
             raise ValueError("engine='plan' needs graph and batch_size")
         self.broadcast_parameters()
@@ -197,17 +224,31 @@ class Trainer:
         float32[B] on the GPU."""
         from . import kernels
         eng = self.engine
-        if self._head_step is None:
-            self._head_step = kernels.LinkHeadStep(eng.batch, self.head.kernel.shape[0] // 2, self.head.kernel,
-                                                   self.head.bias, self.head.kernel.grad, self.head.bias.grad,
-                                                   self.head.kernel.device)
+        self._prepare_head_step()
         # every gradient of the bucket is overwritten by this step's kernels: no zeroing pass
         emb_u, emb_i = eng.forward_train(seeds, walk_ids, rng_seed)
         loss, pred = self._head_step.run(emb_u, emb_i, targets)
         eng.backward(self._head_step.g_user, self._head_step.g_item)
-        self.bucket.all_reduce_mean(self.group)
-        self.opt.step()
+        self.opt.step(grad_scale=self.bucket.all_reduce_sum(self.group))
         return loss, pred.reshape(-1, 1)
+
+    def _prepare_head_step(self):
+        """(Re)builds the prepared head call and drops the engine's prepared weight-gradient calls when the
+        parameters have been moved since they were made (another Trainer built on the same model).
+        Returns True when it did."""
+        from . import kernels
+        if self._head_step is not None and self._head_step.epoch == kernels.storage_epoch():
+            return False
+        eng = self.engine
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() < self.bucket.flat.data_ptr() or \
+                    p.grad.data_ptr() >= self.bucket.flat.data_ptr() + self.bucket.flat.numel() * 4:
+                raise kernels._lib.GsageError("this Trainer's parameters now live in another Trainer's bucket")
+        self._head_step = kernels.LinkHeadStep(eng.batch, self.head.kernel.shape[0] // 2, self.head.kernel,
+                                               self.head.bias, self.head.kernel.grad, self.head.bias.grad,
+                                               self.head.kernel.device)
+        eng._wgrad_pairs = None
+        return True
 
     # -- HIP-graph replay of the step ---------------------------------------------------
     def _graph_body(self, with_update):
@@ -231,10 +272,8 @@ class Trainer:
         from . import kernels
         eng = self.engine
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
-        if self._head_step is None:
-            self._head_step = kernels.LinkHeadStep(eng.batch, self.head.kernel.shape[0] // 2, self.head.kernel,
-                                                   self.head.bias, self.head.kernel.grad, self.head.bias.grad,
-                                                   self.head.kernel.device)
+        if self._prepare_head_step():
+            self._graph = None                               # captured addresses are those of the old layout
         if getattr(self, '_graph', None) is None or self._graph_seed != rng_seed:
             dev = eng.seeds_buf.device
             self._walk_buf = torch.zeros(2 * eng.batch, dtype=torch.int64, device=dev)
@@ -273,9 +312,10 @@ class Trainer:
             if not multi:
                 self.opt.step(launch=False)              # sets the device-side rate for this step
         if multi:
+            # sampling + forward + backward replayed as one graph; then ONE collective (sum) and ONE update
+            # launch that applies 1 / world to the gradients as it reads them
             self._graph.replay()
-            self.bucket.all_reduce_mean(self.group)
-            self.opt.step()
+            self.opt.step(grad_scale=self.bucket.all_reduce_sum(self.group))
         else:
             self._graph.replay()
         return self._head_step.loss, self._head_step.pred.reshape(-1, 1)
@@ -385,24 +425,41 @@ class Trainer:
         batch, y = seq[i]
         return self.head(self.model(batch)), y
 
+    def _inference(self):
+        """Context in which the model runs with dropout off, as Keras runs ``evaluate``, ``predict`` and the
+        validation pass of ``fit`` (``train_movielens.py:200-207``); the training flag is restored after."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            was = self.model.training
+            self.model.eval()
+            try:
+                yield
+            finally:
+                self.model.train(was)
+        return ctx()
+
     @torch.no_grad()
     def evaluate(self, seq):
-        """Loss and metrics of the current weights over a sequence (no update)."""
+        """Loss and metrics of the current weights over a sequence (no update, no dropout)."""
         dev = self.bucket.flat.device
         ys, preds = [], []
-        for i in range(len(seq)):
-            pred, y = self._scores(seq, i)
-            ys.append((y if isinstance(y, torch.Tensor)
-                       else torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)).reshape(-1))
-            preds.append(pred.reshape(-1))
+        with self._inference():
+            for i in range(len(seq)):
+                pred, y = self._scores(seq, i)
+                ys.append((y if isinstance(y, torch.Tensor)
+                           else torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)).reshape(-1))
+                preds.append(pred.reshape(-1))
         out = self._epoch_logs(self._metrics(), ys, preds, None)
         self._raise_sampling_errors()
         return out
 
     @torch.no_grad()
     def predict(self, seq):
-        """Scores of every link of a sequence, in sequence order: float32 [n, 1]."""
-        return torch.cat([self._scores(seq, i)[0] for i in range(len(seq))])
+        """Scores of every link of a sequence, in sequence order: float32 [n, 1] (no dropout)."""
+        with self._inference():
+            return torch.cat([self._scores(seq, i)[0] for i in range(len(seq))])
 
     def step(self, batch, targets):
         self.bucket.zero()

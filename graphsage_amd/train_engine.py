@@ -192,8 +192,8 @@ class SageTrainEngine(SageForwardEngine):
         if f['user'] == f['item']:
             # both node types of a layer have one shape: each layer's weight gradients are one launch (+ one
             # reduction); layer 0 stays on the caller's stream, the small layer 1 goes beside it
-            if self._wgrad_pairs is None:
-                self._wgrad_pairs = [self._wgrad_pair(0), self._wgrad_pair(1)]
+            if self._wgrad_pairs is None or self._wgrad_pairs[0].epoch != kernels.storage_epoch():
+                self._wgrad_pairs = [self._wgrad_pair(0), self._wgrad_pair(1)]   # gradient views of the current layout
             self._side2.wait_stream(main)
             self._wgrad_pairs[0].run()
             with torch.cuda.stream(self._side2):

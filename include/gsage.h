@@ -396,10 +396,14 @@ int gs_link_head_mse_fwd_bwd(const float *emb_user, const float *emb_item, int64
  * p -= lr_t * m / (sqrt(v) + eps), with the caller passing the bias-corrected
  * rate lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) -- by value, or, when
  * lr_t_device != NULL, as a device float read at run time (so a captured HIP
- * graph of the step can be replayed while the rate changes).
+ * graph of the step can be replayed while the rate changes).  Every gradient
+ * is multiplied by grad_scale as it is read (grads itself is left as it is): a
+ * data-parallel job sums its ranks' gradients with one all-reduce and passes
+ * 1 / world here instead of dividing in a pass of its own; 1.0f otherwise.
  */
 int gs_adam_step(float *params, const float *grads, float *m, float *v, int64_t n,
-                 float lr_t, const float *lr_t_device, float beta1, float beta2, float eps, void *stream);
+                 float lr_t, const float *lr_t_device, float beta1, float beta2, float eps,
+                 float grad_scale, void *stream);
 
 /*
  * Hands one batch to a step whose launches are replayed from a captured graph:

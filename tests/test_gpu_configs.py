@@ -1,0 +1,239 @@
+"""Parity on the benchmark's other full-size workloads -- needs a GPU.
+
+Each workload is built exactly as ``bench.py`` builds it (same generator, sizes
+and seeds, taken from ``bench.WORKLOADS``):
+
+* cfg3: power-law on both sides, 10 M users x 1 M items, 500 M edges (1e9 CSR
+  entries; hub degrees far beyond 2**21);
+* cfg4: 100 M users x 10 M items, 2 B edges (4e9 CSR entries: row starts beyond
+  2**32, feature tables beyond 4 GiB);
+* cfg5: the 1 M x 100 k graph with 256-wide features, three hops [25, 10, 5] and
+  256 hidden units (the wide-layer kernel).
+
+Checks per workload, as for the default workload in test_gpu_fullsize.py: every
+walk of a full batch bit-exact against the numpy oracle walk on the same Philox
+draws (neighbor array left on the device, the oracle fetches the entries it
+needs); the engine's main route against an independent route through the
+general kernels; the float64 oracle model on the first links of the batch;
+one training step of the static plan against the autograd route.  The cited
+reference lines are ``sampler.py:54-94`` (walk) and ``models.py:146-190`` /
+``utils.py:103-119`` (model).
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import bench
+import graphsage_amd as ga
+from graphsage_amd import kernels, synthetic
+from graphsage_amd.engine import SageForwardEngine
+from oracle import model as omodel
+from oracle import walker
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x9E3779B97F4A7C15
+# seed edges per batch as bench.py runs each workload; device memory the graph build needs
+CASES = {'cfg3': dict(batch=4096, gib=40), 'cfg4': dict(batch=4096, gib=150), 'cfg5': dict(batch=1024, gib=20)}
+
+
+class _DeviceIndices:
+    """Neighbor array left on the GPU; the oracle fetches the entries it needs."""
+    lazy = True
+
+    def __init__(self, t):
+        self.t = t
+
+    def __getitem__(self, pos):
+        p = torch.from_numpy(np.ascontiguousarray(pos)).to(self.t.device)
+        return self.t[p].cpu().numpy()
+
+
+@pytest.fixture(scope='module', params=sorted(CASES))
+def load(request, cuda):
+    name = request.param
+    cfg, case = bench.WORKLOADS[name], CASES[name]
+    if torch.cuda.get_device_properties(0).total_memory < case['gib'] * 2 ** 30:
+        pytest.skip("%s needs about %d GiB of device memory" % (name, case['gib']))
+    t0 = time.perf_counter()
+    g, u, it = synthetic.power_law_bipartite(cfg['nu'], cfg['ni'], cfg['e'], cfg['fu'], cfg['fi'],
+                                             alpha_item=cfg['alpha_item'], alpha_user=cfg['alpha_user'],
+                                             seed=1234, device=cuda)
+    hu, hi = synthetic.seed_edges(u, it, 1 << 20, seed=0)
+    del u, it
+    torch.cuda.synchronize()
+    print("\n[%s] graph built in %.1f s" % (name, time.perf_counter() - t0), flush=True)
+    b = case['batch']
+    gen = ga.GraphSAGEGenerator(g, b, cfg['fan'], head_node_types=['user', 'item'], seed=SEED)
+    model = ga.GraphSAGE(cfg['layers'], gen, seed=7).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.1, 0.1)                           # a zero bias would hide a misplaced one
+    yield dict(name=name, cfg=cfg, b=b, g=g, hu=hu, hi=hi, gen=gen, model=model, dev=g.device_tensors())
+    del g, hu, hi, gen, model
+    torch.cuda.empty_cache()
+
+
+def _batch(load, k):
+    b = load['b']
+    seeds = torch.cat([load['hu'][k * b:(k + 1) * b], load['hi'][k * b:(k + 1) * b]]).contiguous()
+    e = torch.arange(k * b, (k + 1) * b, dtype=torch.int64, device=seeds.device)
+    return seeds, torch.cat([2 * e, 2 * e + 1]).contiguous()
+
+
+def test_graph_has_the_workloads_size_and_shape(load):
+    cfg, dev = load['cfg'], load['dev']
+    n = cfg['nu'] + cfg['ni']
+    assert dev['indptr'].numel() == n + 1 and int(dev['indptr'][-1]) == 2 * cfg['e'] == dev['indices'].numel()
+    deg = dev['indptr'][1:] - dev['indptr'][:-1]
+    assert int(deg.min()) >= 1                                     # the reference refuses nodes without neighbors
+    if load['name'] == 'cfg3':
+        assert int(deg.max()) > 2 ** 21                            # hubs: degree * random word needs 64-bit products
+    if load['name'] == 'cfg4':
+        assert int(dev['indptr'][-1]) > 2 ** 31 and dev['user'].numel() * 4 > 2 ** 32     # offsets past int32, table past 4 GiB
+    # users' neighbors are items and the other way round (first and last million entries)
+    nu = cfg['nu']
+    assert bool((dev['indices'][:1_000_000] >= nu).all()) and bool((dev['indices'][-1_000_000:] < nu).all())
+
+
+def test_full_batch_walks_equal_the_oracle_bit_for_bit(load):
+    cfg, dev, b = load['cfg'], load['dev'], load['b']
+    seeds, walk_ids = _batch(load, 0)
+    hops, err = kernels.sample(dev['indptr'], dev['indices'], seeds, cfg['fan'], rng_seed=SEED, walk_ids=walk_ids)
+    assert err.tolist() == [0, 0]
+    indptr = dev['indptr'].cpu().numpy()
+    # walk ids 2*edge + side are not consecutive over the batch: the helper below addresses the oracle's
+    # Philox draw by walk id directly
+    want = _oracle_walks(indptr, _DeviceIndices(dev['indices']), seeds.cpu().numpy(), walk_ids.cpu().numpy(), cfg['fan'])
+    for got, w in zip(hops, want):
+        np.testing.assert_array_equal(got.cpu().numpy(), w)
+    nu = cfg['nu']
+    for h, hop in enumerate(hops):                                 # node types alternate with the hop
+        users_first = (h % 2 == 1)
+        assert bool(((hop[:b] < nu) == users_first).all()) and bool(((hop[b:] >= nu) == users_first).all())
+
+
+def _oracle_walks(indptr, indices, roots, walk_ids, fan):
+    """``walker.walk_vectorised`` for arbitrary walk ids: it numbers walks first_walk, first_walk + 1, ...;
+    one call per run of consecutive ids would be slow, so its Philox draw is addressed directly."""
+    from oracle import philox
+    sizes = walker.hop_sizes(fan)
+    frontier = roots.astype(np.int64)[:, None]
+    out = []
+    for h, k in enumerate(fan):
+        parents = np.repeat(frontier, k, axis=1)
+        start = indptr[parents]
+        deg = indptr[parents + 1] - start
+        assert (deg > 0).all()
+        slot = np.arange(sizes[h], dtype=np.int64)[None, :]
+        r = philox.draw_u32(np.broadcast_to(walk_ids[:, None], parents.shape), h,
+                            np.broadcast_to(slot, parents.shape), SEED)
+        frontier = indices[start + philox.index_from_u32(r, deg)].astype(np.int64)
+        out.append(frontier)
+    return out
+
+
+def test_oracle_walk_helper_equals_walk_vectorised_on_consecutive_ids(load):
+    """The helper above is the oracle's own walk when the ids are consecutive."""
+    cfg, dev = load['cfg'], load['dev']
+    seeds, _ = _batch(load, 1)
+    roots = seeds[:64].cpu().numpy()
+    indptr, ind = dev['indptr'].cpu().numpy(), _DeviceIndices(dev['indices'])
+    a = walker.walk_vectorised(indptr, ind, roots, cfg['fan'], rng_seed=SEED, first_walk=1000)
+    c = _oracle_walks(indptr, ind, roots, 1000 + np.arange(64, dtype=np.int64), cfg['fan'])
+    for x, y in zip(a, c):
+        np.testing.assert_array_equal(x, y)
+
+
+def _close(got, want, what):
+    """north_star's bar for fp32 results: 1e-5 relative, element by element, with an absolute floor of
+    1e-6 of the tensor's largest magnitude for elements near zero."""
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    tol = 1e-5 * want.abs() + 1e-6 * float(want.abs().max())
+    bad = (got - want).abs() > tol
+    assert not bool(bad.any()), "%s: %d elements off, worst %.3g" % (
+        what, int(bad.sum()), float(((got - want).abs() / tol).max()))
+
+
+def test_forward_main_route_equals_general_kernels_and_oracle_subset(load):
+    cfg, g, model, b = load['cfg'], load['g'], load['model'], load['b']
+    seeds, walk_ids = _batch(load, 2)
+    eng = SageForwardEngine(g, model, b)
+    alt = SageForwardEngine(g, model, b, use_fused=False)
+    if len(cfg['fan']) == 2:
+        assert eng.walk_kernel                                     # ONE kernel: sample + both layers
+        lay = SageForwardEngine(g, model, b, walk_kernel=False)
+        assert all(lay.fused_layers)
+    else:
+        assert eng.wide_first_layer_only and all(eng.fused_layers)  # sampler + wide layer 0 + general tail
+        lay = None
+    out = [x.clone() for x in eng.forward(seeds, walk_ids, rng_seed=SEED)]
+    out_alt = [x.clone() for x in alt.forward(seeds, walk_ids, rng_seed=SEED)]
+    assert eng.err_flag.tolist() == [0, 0] and alt.err_flag.tolist() == [0, 0]
+    for k in range(2):
+        assert torch.isfinite(out[k]).all()
+        _close(out[k], out_alt[k], "main route vs general kernels [%d]" % k)
+        assert (out[k].double().norm(dim=1) - 1).abs().max().item() <= 1e-5
+    if lay is not None:
+        out_lay = [x.clone() for x in lay.forward(seeds, walk_ids, rng_seed=SEED)]
+        for k in range(2):
+            _close(out[k], out_lay[k], "one kernel vs one kernel per layer [%d]" % k)
+
+    # float64 oracle on the first links of the batch, from the ids the general route sampled;
+    # rows fetched with torch indexing (not this library's gathers)
+    n = 48 if len(cfg['fan']) == 2 else 12
+    nu = cfg['nu']
+    slot_ids = [seeds[:n], seeds[b:b + n]]
+    for hop in alt.hops:
+        slot_ids += [hop[:n].reshape(-1), hop[b:b + n].reshape(-1)]
+    xin = []
+    for s, ids in enumerate(slot_ids):
+        t = ('user', 'item')[(s % 2 + s // 2) % 2]
+        rows = ids.long() - (nu if t == 'item' else 0)
+        x = load['dev'][t][rows].cpu().double()
+        xin.append(x.reshape(n, -1, x.shape[1]))
+    plan = omodel.LayerPlan(cfg['layers'], cfg['fan'], g.node_feature_sizes)
+    weights = {(l, t): {'w_self': a.w_self.detach().cpu().double(), 'w_neigh': a.w_neigh.detach().cpu().double(),
+                        'bias': a.bias.detach().cpu().double()}
+               for l, per in enumerate(model._aggs) for t, a in per.items()}
+    want = omodel.forward(plan, weights, xin)
+    for k in range(2):
+        _close(out[k][:n], want[k], "main route vs float64 oracle [%d]" % k)
+
+
+def test_training_plan_step_equals_autograd_step(load):
+    """One step of sample + forward + backward + Adam through the static plan against the same step through
+    torch.autograd over the general kernels, on the full graph with a reduced batch."""
+    from graphsage_amd.train import LinkHead, Trainer
+    cfg, g = load['cfg'], load['g']
+    b = 256 if len(cfg['fan']) == 2 else 64
+    dev = g.device_tensors()
+    seeds = torch.cat([load['hu'][5000:5000 + b], load['hi'][5000:5000 + b]]).contiguous()
+    walk_ids = torch.arange(2 * b, dtype=torch.int64, device=seeds.device) + (1 << 33)
+    targets = (torch.arange(b, device=seeds.device) % 2).float()
+    results = []
+    for engine in ('autograd', 'plan'):
+        gen = ga.GraphSAGEGenerator(g, b, cfg['fan'], head_node_types=['user', 'item'], seed=3)
+        model = ga.GraphSAGE(cfg['layers'], gen, seed=11).build()
+        tr = Trainer(model, head=LinkHead(cfg['layers'][-1], seeds.device, seed=5), lr=1e-2, engine=engine,
+                     graph=g, batch_size=b)
+        if engine == 'plan':
+            assert tr.engine is not None
+            loss, _ = tr.step_device(seeds, targets, walk_ids, rng_seed=77)
+            assert tr.engine.err_flag.tolist() == [0, 0]
+        else:
+            hops, _ = kernels.sample(dev['indptr'], dev['indices'], seeds, cfg['fan'], rng_seed=77, walk_ids=walk_ids)
+            slot_ids = [seeds[:b].reshape(b, 1), seeds[b:].reshape(b, 1)]
+            for hop in hops:
+                slot_ids += [hop[:b], hop[b:]]
+            batch = ga.BatchFeatures(g, b, slot_ids, gen._slot_types)
+            loss, _ = tr.step(batch, targets)
+        results.append((float(loss), tr.bucket.flat.clone(), [p.detach().clone() for p in tr.params]))
+        del tr, model, gen
+    (l0, g0, p0), (l1, g1, p1) = results
+    assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0))
+    assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
+    for a, c in zip(p0, p1):
+        assert float((a - c).abs().max()) < 2e-4

@@ -21,13 +21,21 @@ RTOL = 1e-5
 
 
 def close(got, want, rtol=RTOL, scale=None):
-    """|got - want| <= rtol * max(|want|) (per tensor): fp32 sums of O(1) terms."""
+    """Two bars, both must hold.  Per tensor: |got - want| <= rtol * max(|want|).  Per element:
+    |got - want| <= rtol * |want| + 0.1 * rtol * max(|want|) -- 1e-5 relative for every element, with an
+    absolute floor of 1e-6 of the tensor's largest magnitude, because an fp32 sum that cancels to
+    (nearly) zero keeps the rounding error of its terms."""
     got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
     want = want.detach().cpu().double().numpy() if isinstance(want, torch.Tensor) else np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, (got.shape, want.shape)
     s = scale if scale is not None else max(float(np.abs(want).max()), 1e-30)
-    err = float(np.abs(got - want).max())
+    diff = np.abs(got - want)
+    err = float(diff.max()) if diff.size else 0.0
     assert err <= rtol * s, "max abs err %.3e > %.1e * %.3e" % (err, rtol, s)
+    tol = rtol * np.abs(want) + 0.1 * rtol * s
+    bad = diff > tol
+    assert not bad.any(), "%d of %d elements beyond %.0e relative (+ %.0e of the scale); worst err/tol %.2f" % (
+        int(bad.sum()), bad.size, rtol, 0.1 * rtol, float((diff / tol).max()))
 
 
 def csr_of(g):
@@ -358,16 +366,19 @@ def test_projection_forward_and_backward(cuda, m, fs, fn, h, act):
     xm.requires_grad_(True)
     want = omodel.aggregator(xs[:, None, :], xm[:, None, None, :], ws, wn, bias, act)[:, 0, :]
     g = torch.randn(m, h, generator=gen, dtype=torch.float64)
+    if act == 'relu':
+        # an output whose pre-activation lies within fp32 rounding of zero may be masked either way:
+        # such elements get no upstream gradient, everything else is compared
+        with torch.no_grad():
+            pre = torch.cat([xs @ ws, xm @ wn], dim=1) + bias
+        g = g * (pre.abs() > 1e-6)
     want.backward(g)
 
     f32 = lambda t: t.detach().float().to(cuda).contiguous()
     out = kernels.sage_project(f32(xs), f32(xm), f32(ws), f32(wn), f32(bias), act)
     scale = float(want.abs().max())
     close(out, want, scale=scale)
-    # the relu mask must come from the oracle's pre-activation sign: away from 0 both agree
     g_ws, g_wn, g_b, g_xs, g_xm = kernels.sage_project_bwd(f32(xs), f32(xm), f32(ws), f32(wn), act, out, f32(g))
-    if act == 'relu' and not bool(((out.cpu() > 0) == (want > 0)).all()):
-        pytest.skip("a pre-activation within rounding of zero: mask differs legitimately")
     close(g_ws, ws.grad)
     close(g_wn, wn.grad)
     close(g_b, bias.grad)

@@ -471,3 +471,112 @@ def test_paired_weight_gradients_equal_two_single_calls(cuda, m, fs, fn, h, act)
         assert torch.equal(p['g_w_self'], g_ws) and torch.equal(p['g_w_neigh'], g_wn)    # same kernels, same order of sums
         if p['g_bias'] is not None:
             assert torch.equal(p['g_bias'], g_b)
+
+
+def test_forward_engine_built_before_the_trainer_follows_the_moved_weights(cuda):
+    """A Trainer moves every parameter into one flat buffer.  A forward engine that ran before that keeps
+    prepared calls holding the old addresses: it must notice and read the weights where they live now."""
+    from graphsage_amd.engine import SageForwardEngine
+    from graphsage_amd.train import LinkHead
+    for f, ns in ((64, [6, 3]), (64, [4, 3, 2])):                  # one-kernel route; one kernel per layer route
+        g, links, targets = _toy(4, fu=f, fi=f)
+        b = 32
+        gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+        model = ga.GraphSAGE([32] * len(ns), gen, seed=11).build()
+        lk = np.asarray(links[:b])
+        seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+        wid = torch.arange(2 * b, dtype=torch.int64, device=cuda)
+        t = torch.from_numpy(targets[:b]).to(cuda)
+        eng = SageForwardEngine(g, model, b)
+        before = [x.clone() for x in eng.forward(seeds, wid, rng_seed=9)]
+        old_ptr = model.parameters()[0].data_ptr()
+        tr = Trainer(model, head=LinkHead(32, cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
+        assert model.parameters()[0].data_ptr() != old_ptr         # the weights did move
+        same = eng.forward(seeds, wid, rng_seed=9)
+        assert torch.equal(same[0], before[0]) and torch.equal(same[1], before[1])
+        for _ in range(3):
+            tr.step_graph(seeds, t, wid, rng_seed=9)
+        after = [x.clone() for x in eng.forward(seeds, wid, rng_seed=9)]
+        assert not torch.equal(after[0], before[0])                # it sees the trained weights ...
+        fresh = SageForwardEngine(g, model, b).forward(seeds, wid, rng_seed=9)
+        assert torch.equal(after[0], fresh[0]) and torch.equal(after[1], fresh[1])   # ... exactly
+        # and the model called on the same sampled batch agrees
+        hops, _ = ga.kernels.sample(g.device_tensors()['indptr'], g.device_tensors()['indices'], seeds, ns, rng_seed=9,
+                                    walk_ids=wid)
+        slot_ids = [seeds[:b].reshape(b, 1), seeds[b:].reshape(b, 1)]
+        for hop in hops:
+            slot_ids += [hop[:b], hop[b:]]
+        with torch.no_grad():
+            emb = model(ga.BatchFeatures(g, b, slot_ids, gen._slot_types))
+        for k in range(2):
+            assert float((emb[k] - after[k]).abs().max()) <= 1e-5
+        # a second Trainer on the same model moves the weights again: the first one notices, too
+        tr2 = Trainer(model, head=tr.head, lr=1e-2, engine='plan', graph=g, batch_size=b)
+        with pytest.raises(ga._lib.GsageError):
+            tr.step_graph(seeds, t, wid, rng_seed=9)
+        loss, _ = tr2.step_graph(seeds, t, wid, rng_seed=9)
+        assert np.isfinite(float(loss))
+
+
+def test_evaluate_and_predict_run_without_dropout(cuda):
+    """Keras runs evaluate, predict and the validation pass of fit with dropout off; the model's training flag
+    (dropout on by default) must not leak into them, and is restored afterwards."""
+    g, links, targets = _toy(1, fu=32, fi=32)
+    gen = ga.GraphSAGEGenerator(g, 16, [3, 2], head_node_types=['user', 'item'], seed=1)
+    model = ga.GraphSAGE([32, 32], gen, dropout=0.5, seed=2)
+    plain = ga.GraphSAGE([32, 32], gen, dropout=0.0, seed=2)
+    from graphsage_amd.train import LinkHead
+    tr = Trainer(model, head=LinkHead(32, cuda, seed=5), lr=1e-2, graph=g, batch_size=16)
+    tr0 = Trainer(plain, head=LinkHead(32, cuda, seed=5), lr=1e-2, graph=g, batch_size=16)
+    seq = gen.flow(links[:64], targets=targets[:64], shuffle=False)
+    seq0 = gen.flow(links[:64], targets=targets[:64], shuffle=False)
+    seq0.salt = seq.salt                                          # same draws for both
+    assert model.training
+    a, b2 = tr.evaluate(seq), tr.evaluate(seq)
+    assert a == b2                                                # deterministic: no dropout mask was drawn
+    assert model.training                                         # flag restored
+    want = tr0.evaluate(seq0)
+    assert abs(a['loss'] - want['loss']) < 1e-6
+    p, p0 = tr.predict(seq), tr0.predict(seq0)
+    assert float((p - p0).abs().max()) < 1e-6
+    # training mode really drops: two passes through the model differ
+    batch, _ = seq[0]
+    x1, x2 = model(batch), model(batch)
+    assert not torch.equal(x1[0], x2[0])
+
+
+def test_sequences_of_one_generator_draw_independently_and_leave_the_walker_seed_alone(cuda):
+    g, links, targets = _toy(2, fu=32, fi=32)
+    gen = ga.GraphSAGEGenerator(g, 16, [5, 3], head_node_types=['user', 'item'], seed=77)
+    walker_seed = gen.sampler.seed
+    first = [x.cpu() for x in gen.sample_features(links[:16], 0).ids]
+    train = gen.flow(links[:64], targets=targets[:64], shuffle=False)
+    test = gen.flow(links[:64], targets=targets[:64], shuffle=False)
+    a, _ = train[0]
+    c, _ = test[0]
+    assert train.salt != test.salt and train.roots(0)[2] != test.roots(0)[2]
+    assert not torch.equal(a.ids[4], c.ids[4])                    # same links, same positions: other neighborhoods
+    a2, _ = train[0]
+    assert all(torch.equal(x, y) for x, y in zip(a.ids, a2.ids))  # a sequence reproduces its own batches
+    assert gen.sampler.seed == walker_seed                        # flow() batches did not re-key the walker
+    gen2 = ga.GraphSAGEGenerator(g, 16, [5, 3], head_node_types=['user', 'item'], seed=77)
+    again = [x.cpu() for x in gen2.sample_features(links[:16], 0).ids]
+    assert all(torch.equal(x, y) for x, y in zip(first, again))   # running-counter calls follow the constructor seed
+
+
+def test_adam_kernel_scales_the_gradients_it_reads(cuda):
+    """grad_scale = 1 / world after a summing all-reduce equals dividing first."""
+    from graphsage_amd import kernels
+    gen = torch.Generator().manual_seed(3)
+    n = 5000
+    p0, gsum = torch.randn(n, generator=gen).to(cuda), (torch.randn(n, generator=gen) * 8).to(cuda)
+    a = [p0.clone(), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)]
+    c = [p0.clone(), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)]
+    keep = gsum.clone()
+    for t in range(1, 4):
+        lr_t = 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        kernels.adam_step(a[0], gsum, a[1], a[2], lr_t, 0.9, 0.999, 1e-7, grad_scale=0.125)
+        kernels.adam_step(c[0], gsum * 0.125, c[1], c[2], lr_t, 0.9, 0.999, 1e-7)
+    assert torch.equal(gsum, keep)                                # the gradient buffer is only read
+    for x, y in zip(a, c):
+        assert torch.equal(x, y)                                  # 1/8 is exact in fp32: same bits
