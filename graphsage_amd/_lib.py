@@ -93,6 +93,8 @@ SIGNATURES['gs_link_head_workspace'] = (_sz, [_i64, _i32])
 SIGNATURES['gs_link_head_fwd'] = (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp])
 SIGNATURES['gs_link_head_mse_fwd_bwd'] = (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                  _vp, _sz, _vp])
+SIGNATURES['gs_link_head_mse_fwd_bwd_static'] = (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                        _vp])
 SIGNATURES['gs_stage_batch'] = (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _f32, _vp, _vp])
 SIGNATURES['gs_adam_step'] = (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _vp, _f32, _f32, _f32, _f32, _vp])
 

@@ -11,6 +11,8 @@
 // gs_adam_step is the Keras/TF2 Adam update on flat parameter storage.
 #include "gs_common.h"
 
+#include <atomic>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -182,6 +184,60 @@ extern "C" int gs_link_head_mse_fwd_bwd(const float *emb_user, const float *emb_
                        static_cast<const float *>(workspace), blocks,
                        2 * E, 1.f / (float)B, g_kernel, g_bias, loss);
     return gs::check_launch("gs_link_head_mse_fwd_bwd (reduce)");
+}
+
+// ---- the same step for callers that cannot allocate ---------------------------------------
+// The slab of per-block partial sums lives in device memory that belongs to the library's code
+// object: every GPU the library runs on holds its own copy at its own address until the process
+// ends.  Largest case: 256 blocks x (2 * 256 + 2) floats = 526 336 bytes.
+constexpr int kStaticBlocks = 256;                       // head_blocks() never exceeds it
+constexpr int kStaticMaxE = 256;                         // = kMaxCols * 32, the widest embedding of the kernels above
+constexpr size_t kStaticFloats = (size_t)kStaticBlocks * (2 * kStaticMaxE + 2);
+
+static __device__ __align__(256) float scratch[kStaticFloats];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::atomic<float *> g_scratch_ptr[kMaxDevices];         // device address of `scratch`, per GPU
+
+// The array's name is only a handle on the host; its address on the current GPU comes from the
+// runtime, once per device (no allocation, nothing enqueued).
+int static_scratch(float **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_link_head_mse_fwd_bwd_static: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return gs::fail(GS_ELIMIT, "gs_link_head_mse_fwd_bwd_static: device %d beyond %d", dev, kMaxDevices);
+    float *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return gs::fail(GS_ELAUNCH, "gs_link_head_mse_fwd_bwd_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev].store(p, std::memory_order_release);      // every thread finds the same address
+    }
+    *out = p;
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" int gs_link_head_mse_fwd_bwd_static(const float *emb_user, const float *emb_item, int64_t B, int E,
+                                               const float *kernel, const float *bias, const float *targets,
+                                               float *pred, float *loss, float *g_emb_user, float *g_emb_item,
+                                               float *g_kernel, float *g_bias, void *stream) {
+    if (B < 1 || E < 1) return gs::fail(GS_EINVAL, "gs_link_head_mse_fwd_bwd_static: B=%lld E=%d", (long long)B, E);
+    if (E > kStaticMaxE)
+        return gs::fail(GS_ELIMIT, "gs_link_head_mse_fwd_bwd_static: embedding width %d exceeds the %d the static scratch "
+                                   "(%zu bytes) is sized for", E, kStaticMaxE, kStaticFloats * sizeof(float));
+    const int blocks = head_blocks(B);
+    if (blocks > kStaticBlocks || (size_t)blocks * (size_t)(2 * E + 2) > kStaticFloats)
+        return gs::fail(GS_ELIMIT, "gs_link_head_mse_fwd_bwd_static: %d blocks of %d floats exceed the static scratch", blocks, 2 * E + 2);
+    float *slab = nullptr;
+    if (int rc = static_scratch(&slab)) return rc;
+    // every block writes its whole slab row before the reduction reads rows [0, blocks): nothing of an
+    // earlier call is read, so nothing needs clearing
+    return gs_link_head_mse_fwd_bwd(emb_user, emb_item, B, E, kernel, bias, targets, pred, loss, g_emb_user, g_emb_item,
+                                    g_kernel, g_bias, slab, (size_t)blocks * (size_t)(2 * E + 2) * sizeof(float), stream);
 }
 
 extern "C" int gs_adam_step(float *params, const float *grads, float *m, float *v, int64_t n,

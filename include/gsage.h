@@ -391,6 +391,24 @@ int gs_link_head_mse_fwd_bwd(const float *emb_user, const float *emb_item, int64
                              void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * gs_link_head_mse_fwd_bwd for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving or training loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same arguments minus the
+ * workspace: the per-block partial sums go to a static device array inside the
+ * library (526 336 bytes, held by every GPU the library runs on until the process
+ * ends), whose address on the current device is looked up on the first call on
+ * that device.  The call allocates and frees nothing.  Limit: E <= 256 (the
+ * width the array is sized for; any B), else GS_ELIMIT.  All calls on one GPU
+ * share that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race; calls ordered on one stream do not.  Results are bitwise those
+ * of gs_link_head_mse_fwd_bwd.
+ */
+int gs_link_head_mse_fwd_bwd_static(const float *emb_user, const float *emb_item, int64_t B, int E,
+                                    const float *kernel, const float *bias, const float *targets,
+                                    float *pred, float *loss, float *g_emb_user, float *g_emb_item,
+                                    float *g_kernel, float *g_bias, void *stream);
+
+/*
  * Adam update on flat storage, the optimizer of train_movielens.py:185 in the
  * TF2/Keras formulation: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
  * p -= lr_t * m / (sqrt(v) + eps), with the caller passing the bias-corrected
