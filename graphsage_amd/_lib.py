@@ -60,6 +60,23 @@ SIGNATURES['gs_sage_fused_fwd'] = (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _i32
 
 
 
+class FusedSampling(_c.Structure):
+    """gs_fused_sampling of include/gsage.h."""
+    _fields_ = [('indptr', _vp), ('indices', _vp), ('n_nodes', _i64), ('rng_seed', _u64), ('walk_id_base', _u64),
+                ('walk_ids', _vp), ('replay', _vp), ('tape_len', _i64), ('err_flag', _vp)]
+
+
+class FusedDraw(_c.Structure):
+    """gs_fused_draw of include/gsage.h."""
+    _fields_ = [('hop', _c.c_int32), ('heads_per_walk', _c.c_int32), ('tape_off', _c.c_int32), ('walk0', _i64),
+                ('out_child_ids', _vp)]
+
+
+SIGNATURES['gs_sage_fused_sampled_fwd'] = (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i64,
+                                                  _c.POINTER(FusedSegment), _i32, _vp, _vp, _vp, _i32, _i32, _i32,
+                                                  _vp, _vp, _vp, _c.POINTER(FusedSampling), _c.POINTER(FusedDraw), _vp])
+
+
 class WgradProblem(_c.Structure):
     """gs_wgrad_problem of include/gsage.h."""
     _fields_ = [('x_self', _vp), ('x_mean', _vp), ('out', _vp), ('g_out', _vp), ('g_W_self', _vp), ('g_W_neigh', _vp),

@@ -57,7 +57,86 @@ struct FusedShape {
     }
 };
 
-template <int FS, int FN, int HH, bool DENSE>
+constexpr int kDrawChunks = 2;                               // x 64 draws of a tile kept in flight in registers
+
+// Draws of up to kDrawChunks * 64 children of one tile, in three steps so that the two dependent reads
+// of a draw (row bounds, then the neighbor) can be spread over other work.
+struct DrawRegs {
+    int32_t hid[kDrawChunks];
+    int64_t ra[kDrawChunks], rb[kDrawChunks];
+    int32_t v[kDrawChunks];
+};
+
+__device__ __forceinline__ int find_seg(const FusedArgs &a, long long tile) {
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < kMaxSegs; ++s)
+        if (s < a.n_segs && tile >= a.seg[s].tile0) si = s;
+    return si;
+}
+
+// step 1: the heads' ids and their adjacency row bounds (child i of the tile belongs to head i / n)
+__device__ __forceinline__ void draw_bounds(const gs::Draws &d, const Seg &sg, long long p0, int cnt, int n, int base,
+                                            int lane, DrawRegs &q) {
+#pragma unroll
+    for (int c = 0; c < kDrawChunks; ++c) {
+        const int i = base + c * 64 + lane;
+        q.hid[c] = -1;
+        if (i < cnt) q.hid[c] = sg.head_ids[p0 + (unsigned)i / (unsigned)n];
+        if ((unsigned long long)(long long)q.hid[c] >= (unsigned long long)d.n_nodes) q.hid[c] = -1;
+        const int32_t pc = q.hid[c] >= 0 ? q.hid[c] : 0;     // node 0 stands in for dead slots
+        q.ra[c] = d.indptr[pc];
+        q.rb[c] = d.indptr[pc + 1];
+    }
+}
+
+// step 2: the random word of each draw (Philox counter (walk, hop, slot) or tape word) and the neighbor read
+__device__ __forceinline__ void draw_ids(const gs::Draws &d, const Seg &sg, long long p0, int cnt, int n, int base,
+                                         int lane, DrawRegs &q) {
+    const unsigned hpw = (unsigned)sg.heads_per_walk;
+    const long long w0 = sg.walk0 + p0 / (long long)hpw;    // wave-uniform
+    const unsigned j0 = (unsigned)(p0 % (long long)hpw);
+#pragma unroll
+    for (int c = 0; c < kDrawChunks; ++c) {
+        const int i = base + c * 64 + lane;
+        const unsigned pp = (unsigned)i / (unsigned)n, cc = (unsigned)i - pp * (unsigned)n;
+        const unsigned jj = j0 + pp;
+        const unsigned dw = jj / hpw;
+        const long long w = w0 + dw;
+        const unsigned t = (jj - dw * hpw) * (unsigned)n + cc;               // slot inside the walk's hop
+        uint32_t r = 0;
+        if (i < cnt) {
+            if (d.replay) r = d.replay[(size_t)w * d.tape_len + sg.tape_off + t];
+            else {
+                const unsigned long long walk = d.walk_ids ? (unsigned long long)d.walk_ids[w]
+                                                           : d.walk_base + (unsigned long long)w;
+                r = gs::philox4x32_10_x((uint32_t)walk, (uint32_t)(walk >> 32), (uint32_t)sg.hop, t, d.key0, d.key1);
+            }
+        }
+        const uint32_t deg = (uint32_t)(q.rb[c] - q.ra[c]);
+        const bool live = q.hid[c] >= 0 && deg != 0;
+        if (q.hid[c] >= 0 && deg == 0) atomicMax(&d.err[0], q.hid[c] + 1);
+        q.v[c] = d.indices[live ? q.ra[c] + (int64_t)__umulhi(r, deg) : 0];
+        if (!live) q.v[c] = -1;
+    }
+}
+
+// step 3: the ids into the wave's LDS tile (and into memory when the caller wants them)
+__device__ __forceinline__ void draw_store(const Seg &sg, long long p0, int cnt, int n, int base, int lane,
+                                           const DrawRegs &q, int32_t *s_child) {
+#pragma unroll
+    for (int c = 0; c < kDrawChunks; ++c) {
+        const int i = base + c * 64 + lane;
+        if (i < cnt) {
+            s_child[i] = q.v[c];
+            if (sg.out_child_ids) sg.out_child_ids[p0 * n + i] = q.v[c];
+        }
+    }
+}
+
+// SAMPLED: segments with hop >= 0 draw their children's ids in the kernel (the deepest hop of a walk,
+// most of its samples) exactly as gs_sample would: same CSR reads, same Philox counter or tape word.
+template <int FS, int FN, int HH, bool DENSE, bool SAMPLED = false>
 __global__ __launch_bounds__(kWaves * 64, 4)
 void sage_fused_kernel(const FusedArgs a) {
     static_assert(FS % 16 == 0 && FN % 16 == 0 && HH % 16 == 0, "widths must be multiples of 16");
@@ -96,12 +175,11 @@ void sage_fused_kernel(const FusedArgs a) {
         for (int ct = 0; ct < NT; ++ct) bias_v[hf][ct] = a.bias ? a.bias[hf * HH + ct * 16 + r] : 0.f;
     __syncthreads();
 
-    for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < a.n_tiles;
-         tile += (long long)gridDim.x * kWaves) {
-        int si = 0;
-#pragma unroll
-        for (int s = 1; s < kMaxSegs; ++s)
-            if (s < a.n_segs && tile >= a.seg[s].tile0) si = s;
+    const long long stride = (long long)gridDim.x * kWaves;
+    DrawRegs pre{};                                          // draws of this wave's next tile, in flight
+    bool have_ids = false;                                   // ... and whether `pre` holds this tile's ids
+    for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < a.n_tiles; tile += stride) {
+        const int si = find_seg(a, tile);
         const Seg &sg = a.seg[si];
         const int32_t *head_ids = sg.head_ids;
         const int32_t *child_ids = sg.child_ids;
@@ -113,7 +191,21 @@ void sage_fused_kernel(const FusedArgs a) {
 
         // 1. ids
         wave_lds_fence();                                   // previous tile's LDS reads are done
-        if (!DENSE) {
+        if (SAMPLED && sg.hop >= 0) {
+            // Children of this tile's heads are drawn here, exactly as gs_sample draws them.  Usually
+            // they were requested while the previous tile's rows were being gathered (`pre`);
+            // otherwise (first tile of the wave, very wide fan-outs) chunk by chunk on the spot.
+            if (have_ids) {
+                draw_store(sg, p0, np * n, n, 0, lane, pre, s_child);
+            } else {
+                for (int base = 0; base < np * n; base += 64 * kDrawChunks) {
+                    DrawRegs now{};
+                    draw_bounds(a.draws, sg, p0, np * n, n, base, lane, now);
+                    draw_ids(a.draws, sg, p0, np * n, n, base, lane, now);
+                    draw_store(sg, p0, np * n, n, base, lane, now, s_child);
+                }
+            }
+        } else if (!DENSE) {
             const int32_t *src = child_ids + p0 * n;
             for (int i = lane; i < np * n; i += 64) s_child[i] = src[i];
         }
@@ -124,6 +216,21 @@ void sage_fused_kernel(const FusedArgs a) {
             s_head[lane] = (int32_t)row;
         }
         wave_lds_fence();
+
+        // 1b. the next tile's draws: its heads' row bounds are requested now and arrive under the
+        // first round of row gathers below; the neighbor reads follow after that round.
+        bool ahead = false;
+        long long p0n = 0;
+        int cntn = 0, nn = 1, sin = 0;
+        if (SAMPLED && tile + stride < a.n_tiles) {
+            sin = find_seg(a, tile + stride);
+            const Seg &sn = a.seg[sin];
+            p0n = (tile + stride - sn.tile0) * 16;
+            nn = sn.n_child;
+            cntn = (int)min((long long)16, sn.n_heads - p0n) * nn;
+            ahead = sn.hop >= 0 && cntn <= 64 * kDrawChunks;
+            if (ahead) draw_bounds(a.draws, sn, p0n, cntn, nn, 0, lane, pre);
+        }
 
         // 2. own rows: issue the loads, consume them after the mean phase.  Invalid rows read
         // row 0 and are zeroed by a select, so the load stream has no branches.
@@ -136,44 +243,58 @@ void sage_fused_kernel(const FusedArgs a) {
             own[pass] = row >= 0 ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 
-        // 3. neighbor means -> A
+        // 3. neighbor means -> A.  Lane group g owns heads g, g + GN, ...; their children form one
+        // list of HPG * n rows that is fetched kUnroll rows at a time whatever the fan-out (two heads
+        // per round at n = 5), and summed in child order; a head's mean leaves when its last child
+        // has been added.
         {
+            constexpr int HPG = 16 / GN;
             const int g = lane / FNV, c = lane % FNV;
             const float denom = (float)n;
-            const int rounds = (n + kUnroll - 1) / kUnroll;
-            const int per = (n + rounds - 1) / rounds;
+            const int R = HPG * n;
+            const int rounds = (R + kUnroll - 1) / kUnroll;
+            const int per = (R + rounds - 1) / rounds;
             const float4 *table = reinterpret_cast<const float4 *>(a.feat_neigh) + c;
-            for (int pp = g; pp < 16; pp += GN) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pp < np) {
-                    const int32_t *ids = s_child + pp * n;
-                    const long long dense0 = child_row0 + (p0 + pp) * n;
-                    for (int j0 = 0; j0 < n; j0 += per) {
-                        float4 v[kUnroll];
-                        unsigned okmask = 0;
+            int kl = 0, jl = 0;                              // head / child the load stream is at
+            int ka = 0, ja = 0;                              // ... and the sum
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int f0 = 0; f0 < R; f0 += per) {
+                float4 v[kUnroll];
+                unsigned okmask = 0;
 #pragma unroll
-                        for (int u = 0; u < kUnroll; ++u) {
-                            const int j = min(j0 + u, n - 1);
-                            const long long rw = DENSE ? dense0 + j : (long long)ids[j] - a.off_neigh;
-                            const bool ok = (u < per) && (j0 + u < n) &&
-                                            ((unsigned long long)rw < (unsigned long long)a.n_rows_neigh);
-                            okmask |= (unsigned)ok << u;
-                            v[u] = table[(ok ? rw : 0) * FNV];
-                        }
-#pragma unroll
-                        for (int u = 0; u < kUnroll; ++u) {
-                            const bool ok = (okmask >> u) & 1;
-                            acc.x += ok ? v[u].x : 0.f; acc.y += ok ? v[u].y : 0.f;
-                            acc.z += ok ? v[u].z : 0.f; acc.w += ok ? v[u].w : 0.f;
-                        }
-                    }
-                    acc.x /= denom; acc.y /= denom; acc.z /= denom; acc.w /= denom;
-                    if (a.save_mean)
-                        reinterpret_cast<float4 *>(a.save_mean + (size_t)(out_row0 + p0 + pp) * FN)[c] = acc;
+                for (int u = 0; u < kUnroll; ++u) {
+                    const bool in = (u < per) && (f0 + u < R);
+                    const int pp = g + kl * GN;
+                    const bool head_ok = in && pp < np;
+                    long long rw = -1;
+                    if (DENSE) rw = child_row0 + (p0 + pp) * n + jl;
+                    else if (head_ok) rw = (long long)s_child[pp * n + jl] - a.off_neigh;
+                    const bool ok = head_ok && ((unsigned long long)rw < (unsigned long long)a.n_rows_neigh);
+                    okmask |= (unsigned)ok << u;
+                    v[u] = table[(ok ? rw : 0) * FNV];
+                    if (in && ++jl == n) { jl = 0; ++kl; }
                 }
-                *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) = acc;
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const bool in = (u < per) && (f0 + u < R);
+                    const bool ok = (okmask >> u) & 1;
+                    acc.x += ok ? v[u].x : 0.f; acc.y += ok ? v[u].y : 0.f;
+                    acc.z += ok ? v[u].z : 0.f; acc.w += ok ? v[u].w : 0.f;
+                    if (in && ++ja == n) {
+                        const int pp = g + ka * GN;
+                        acc.x /= denom; acc.y /= denom; acc.z /= denom; acc.w /= denom;
+                        if (a.save_mean && pp < np)
+                            reinterpret_cast<float4 *>(a.save_mean + (size_t)(out_row0 + p0 + pp) * FN)[c] = acc;
+                        *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) = acc;
+                        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                        ja = 0; ++ka;
+                    }
+                }
+                if (SAMPLED && ahead && f0 == 0)             // the next tile's row bounds have arrived
+                    draw_ids(a.draws, a.seg[sin], p0n, cntn, nn, 0, lane, pre);
             }
         }
+        have_ids = ahead;
         wave_lds_fence();
 
         // 4a. neighbor half.  The fragment offset goes through an empty asm so the weight
@@ -263,7 +384,11 @@ int launch(const FusedArgs &a, hipStream_t stream) {
     long long blocks = (a.n_tiles + kWaves - 1) / kWaves;
     const long long cap = 256 * 8;                      // a few blocks per CU; waves loop over tiles
     if (blocks > cap) blocks = cap;
-    if (a.seg[0].child_ids)
+    bool sampled = false;
+    for (int s = 0; s < a.n_segs; ++s) sampled |= a.seg[s].hop >= 0;
+    if (sampled)
+        gs::launch_timed(sage_fused_kernel<FS, FN, HH, false, true>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
+    else if (a.seg[0].child_ids)
         gs::launch_timed(sage_fused_kernel<FS, FN, HH, false>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
     else
         gs::launch_timed(sage_fused_kernel<FS, FN, HH, true>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, stream, a);
@@ -292,12 +417,43 @@ extern "C" int gs_sage_fused_supported(int Fs, int Fn, int H, int max_child) {
     return narrow_supported(Fs, Fn, H, max_child) || gs::sage_wide_supported(Fs, Fn, H, max_child);
 }
 
+static int fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
+                     const float *feat_neigh, int64_t n_rows_neigh, int Fn, int64_t off_neigh,
+                     const gs_fused_segment *segs, int n_segs,
+                     const float *W_self, const float *W_neigh, const float *bias,
+                     int H, int act, int normalize,
+                     float *out, float *save_self, float *save_mean,
+                     const gs_fused_sampling *sampling, const gs_fused_draw *draws, void *stream);
+
 extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
                                  const float *feat_neigh, int64_t n_rows_neigh, int Fn, int64_t off_neigh,
                                  const gs_fused_segment *segs, int n_segs,
                                  const float *W_self, const float *W_neigh, const float *bias,
                                  int H, int act, int normalize,
                                  float *out, float *save_self, float *save_mean, void *stream) {
+    return fused_fwd(feat_self, n_rows_self, Fs, off_self, feat_neigh, n_rows_neigh, Fn, off_neigh, segs, n_segs,
+                     W_self, W_neigh, bias, H, act, normalize, out, save_self, save_mean, nullptr, nullptr, stream);
+}
+
+extern "C" int gs_sage_fused_sampled_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
+                                         const float *feat_neigh, int64_t n_rows_neigh, int Fn, int64_t off_neigh,
+                                         const gs_fused_segment *segs, int n_segs,
+                                         const float *W_self, const float *W_neigh, const float *bias,
+                                         int H, int act, int normalize,
+                                         float *out, float *save_self, float *save_mean,
+                                         const gs_fused_sampling *sampling, const gs_fused_draw *draws, void *stream) {
+    if (!sampling || !draws) return gs::fail(GS_EINVAL, "gs_sage_fused_sampled_fwd: sampling and draws must be given");
+    return fused_fwd(feat_self, n_rows_self, Fs, off_self, feat_neigh, n_rows_neigh, Fn, off_neigh, segs, n_segs,
+                     W_self, W_neigh, bias, H, act, normalize, out, save_self, save_mean, sampling, draws, stream);
+}
+
+static int fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
+                     const float *feat_neigh, int64_t n_rows_neigh, int Fn, int64_t off_neigh,
+                     const gs_fused_segment *segs, int n_segs,
+                     const float *W_self, const float *W_neigh, const float *bias,
+                     int H, int act, int normalize,
+                     float *out, float *save_self, float *save_mean,
+                     const gs_fused_sampling *sampling, const gs_fused_draw *draws, void *stream) {
     if (n_segs < 0 || n_segs > kMaxSegs) return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: n_segs=%d outside [0,%d]", n_segs, kMaxSegs);
     if (act != GS_ACT_LINEAR && act != GS_ACT_RELU) return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: unknown activation %d", act);
     FusedArgs a{};
@@ -309,14 +465,31 @@ extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, in
         if (g.n_heads < 0 || g.n_child < 1) return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: segment %d has n_heads=%lld n_child=%d", s, (long long)g.n_heads, g.n_child);
         if (!g.head_ids && (g.self_row0 < 0 || g.self_row0 + g.n_heads > n_rows_self))
             return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: segment %d dense head rows exceed feat_self", s);
-        if (!g.child_ids && (g.child_row0 < 0 || g.child_row0 + g.n_heads * g.n_child > n_rows_neigh))
+        const bool drawn = draws && draws[s].hop >= 0;
+        if (!drawn && !g.child_ids && (g.child_row0 < 0 || g.child_row0 + g.n_heads * g.n_child > n_rows_neigh))
             return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: segment %d dense child rows exceed feat_neigh", s);
-        if (s > 0 && (g.child_ids == nullptr) != (segs[0].child_ids == nullptr))
+        if (!draws && s > 0 && (g.child_ids == nullptr) != (segs[0].child_ids == nullptr))
             return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: segments must all give child ids or all be dense");
+        if (draws && !drawn && !g.child_ids)
+            return gs::fail(GS_EINVAL, "gs_sage_fused_sampled_fwd: segment %d neither draws its children nor gives child ids", s);
         Seg &d = a.seg[s];
         d.head_ids = g.head_ids; d.child_ids = g.child_ids; d.n_heads = g.n_heads;
         d.self_row0 = g.self_row0; d.child_row0 = g.child_row0; d.n_child = g.n_child;
         d.tile0 = tiles; d.out_row0 = rows;
+        d.hop = -1; d.heads_per_walk = 1; d.tape_off = 0; d.walk0 = 0; d.out_child_ids = nullptr;
+        if (drawn) {
+            const gs_fused_draw &w = draws[s];
+            if (!g.head_ids) return gs::fail(GS_EINVAL, "gs_sage_fused_sampled_fwd: segment %d draws children but gives no head ids", s);
+            if (w.hop >= GS_MAX_HOPS || w.heads_per_walk < 1 || w.walk0 < 0 || w.tape_off < 0)
+                return gs::fail(GS_EINVAL, "gs_sage_fused_sampled_fwd: segment %d: hop=%d heads_per_walk=%d walk0=%lld tape_off=%d",
+                                s, w.hop, w.heads_per_walk, (long long)w.walk0, w.tape_off);
+            if ((long long)w.heads_per_walk * g.n_child > (1 << 24))
+                return gs::fail(GS_ELIMIT, "gs_sage_fused_sampled_fwd: segment %d has more than 2^24 slots per walk", s);
+            if (sampling->replay && (long long)w.tape_off + (long long)w.heads_per_walk * g.n_child > sampling->tape_len)
+                return gs::fail(GS_EINVAL, "gs_sage_fused_sampled_fwd: segment %d reads past a walk's tape", s);
+            d.hop = w.hop; d.heads_per_walk = w.heads_per_walk; d.tape_off = w.tape_off; d.walk0 = w.walk0;
+            d.out_child_ids = w.out_child_ids;
+        }
         tiles += (g.n_heads + 15) / 16;
         rows += g.n_heads;
         if (g.n_child > max_child) max_child = g.n_child;
@@ -336,8 +509,26 @@ extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, in
     a.W_self = W_self; a.W_neigh = W_neigh; a.bias = bias;
     a.out = out; a.save_self = save_self; a.save_mean = save_mean;
     a.n_segs = n_segs; a.n_tiles = tiles; a.act = act; a.normalize = normalize; a.max_child = max_child;
+    bool any_drawn = false;
+    for (int i = 0; i < n_segs; ++i) any_drawn |= a.seg[i].hop >= 0;
+    if (any_drawn) {
+        if (!sampling->indptr || !sampling->indices || !sampling->err_flag)
+            return gs::fail(GS_EINVAL, "gs_sage_fused_sampled_fwd: null pointer in the sampling descriptor");
+        if (sampling->n_nodes <= 0 || sampling->n_nodes > 0x7FFFFFFELL)
+            return gs::fail(GS_EINVAL, "gs_sage_fused_sampled_fwd: n_nodes=%lld out of range", (long long)sampling->n_nodes);
+        if (sampling->replay && sampling->tape_len < 1)
+            return gs::fail(GS_EINVAL, "gs_sage_fused_sampled_fwd: a replay tape needs its length per walk");
+        a.draws.indptr = sampling->indptr; a.draws.indices = sampling->indices; a.draws.n_nodes = sampling->n_nodes;
+        a.draws.key0 = (uint32_t)sampling->rng_seed; a.draws.key1 = (uint32_t)(sampling->rng_seed >> 32);
+        a.draws.walk_base = sampling->walk_id_base; a.draws.walk_ids = sampling->walk_ids;
+        a.draws.replay = sampling->replay; a.draws.tape_len = sampling->tape_len; a.draws.err = sampling->err_flag;
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (!narrow_supported(Fs, Fn, H, max_child)) return gs::sage_wide_fwd(a, Fs, Fn, H, s);   // wide layers: wide.hip
+    if (!narrow_supported(Fs, Fn, H, max_child)) {                                            // wide layers: wide.hip
+        if (any_drawn) return gs::fail(GS_ELIMIT, "gs_sage_fused_sampled_fwd: the wide-layer kernel reads child ids; "
+                                                  "run gs_sample for every hop and use gs_sage_fused_fwd");
+        return gs::sage_wide_fwd(a, Fs, Fn, H, s);
+    }
     const int hh = H / 2;
 #define GS_CASE(fs, fn, h2) if (Fs == fs && Fn == fn && hh == h2) return launch<fs, fn, h2>(a, s);
     GS_CASE(64, 64, 16) GS_CASE(64, 64, 32)

@@ -17,6 +17,25 @@ struct Seg {
     long long tile0;           // index of the segment's first tile
     long long out_row0;        // first output row of the segment
     int n_child;
+    // children drawn inside the kernel (hop >= 0) instead of read from child_ids:
+    int hop;                   // the draws are gs_sample's hop `hop` (-1: not drawn)
+    int heads_per_walk;        // heads of this segment per walk (= size of the walk's hop `hop`-1, 1 for the roots)
+    int tape_off;              // offset of hop `hop` inside one walk's replay tape
+    long long walk0;           // index of the walk head 0 belongs to (row of walk_ids / of the tape)
+    int32_t *out_child_ids;    // nullable: receives the drawn ids [n_heads * n_child]
+};
+
+// What the in-kernel draws read: the adjacency and the keys of gs_sample.
+struct Draws {
+    const int64_t *indptr;
+    const int32_t *indices;
+    long long n_nodes;
+    uint32_t key0, key1;
+    unsigned long long walk_base;
+    const int64_t *walk_ids;
+    const uint32_t *replay;
+    long long tape_len;
+    int32_t *err;
 };
 
 struct FusedArgs {
@@ -28,6 +47,7 @@ struct FusedArgs {
     int n_segs;
     long long n_tiles;
     int act, normalize, max_child;
+    Draws draws;               // used when some segment has hop >= 0
 };
 
 // Wide layers (wide.hip).  `a.seg[].tile0` / `a.n_tiles` are recomputed for 128-head tiles.

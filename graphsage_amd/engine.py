@@ -30,8 +30,15 @@ _TYPES = ('user', 'item')
 
 
 class SageForwardEngine:
-    def __init__(self, graph, model, batch_size, use_fused=True, walk_kernel=True):
+    def __init__(self, graph, model, batch_size, use_fused=True, walk_kernel=True, keep_ids=False, draw_in_layer=False):
+        """draw_in_layer: the layer-0 kernel draws the deepest hop's ids itself instead of reading what
+        the sampler kernel wrote (``gs_sage_fused_sampled_fwd``); keep_ids then also leaves those ids
+        in ``hops[-1]``.  Off by default: a draw costs one 64-byte sector of the neighbor array wherever
+        it is made, and on a graph whose neighbor array exceeds the caches the sampler kernel, which
+        does nothing else, moves those sectors faster (measured on the 1M x 100k graph, fan-outs
+        25/10/5: 765 us per step against 872 us)."""
         self.graph = graph
+        self.keep_ids = bool(keep_ids)
         self.model = model.build()
         self.fanouts = [int(n) for n in model.n_samples]
         self.n_hops = len(self.fanouts)
@@ -115,6 +122,13 @@ class SageForwardEngine:
                 self.walk_kernel = True
         self._walk_call = None
         self.emb_all = torch.empty((2 * b, model.dims[-1]['user']), dtype=torch.float32, device=device)
+        # On request (draw_in_layer) the deepest hop -- most of a walk's samples -- is drawn by the
+        # layer-0 kernel where its feature rows are gathered, and the sampler kernel stops one hop short.
+        # (The wide-layer kernel reads ids, so wide models always sample every hop up front.)
+        self.draw_deepest = bool(draw_in_layer and use_fused and all(self.fused_layers) and not self.walk_kernel
+                                 and not self.wide_first_layer_only
+                                 and all(model.dims[1][t] // 2 in (16, 32) for t in _TYPES))
+        self._step_keys = (0, None, None)
 
     def _arm_probe(self):
         """The next dominant-kernel launch carries a pair of HIP events in its own
@@ -143,8 +157,17 @@ class SageForwardEngine:
             raise ValueError("walk_ids must be int64, one per seed")
         if replay is not None and replay.numel() != seeds.numel() * sum(self.sizes[1:]):
             raise ValueError("replay tape has the wrong length")
+        self._step_keys = (rng_seed, walk_ids, replay)
+        n_hops = self.n_hops
+        if self.draw_deepest:
+            n_hops -= 1                                      # the layer-0 kernel draws the last hop
+            if n_hops == 0:
+                return
+            if replay is not None:                           # the sampler strides the tape by ITS hops' words
+                t_all, t_part = sum(self.sizes[1:]), sum(self.sizes[1:n_hops + 1])
+                replay = replay.reshape(seeds.numel(), t_all)[:, :t_part].contiguous().reshape(-1)
         check(lib.gs_sample(ptr(self.indptr), ptr(self.indices), self.indptr.numel() - 1, ptr(seeds),
-                            seeds.numel(), self._fan_arr, self.n_hops, int(rng_seed) & 0xFFFFFFFFFFFFFFFF, 0,
+                            seeds.numel(), self._fan_arr, n_hops, int(rng_seed) & 0xFFFFFFFFFFFFFFFF, 0,
                             ptr(walk_ids), ptr(replay), self._hop_ptrs, ptr(self.err_flag), stream_handle()),
               'gs_sample')
 
@@ -221,17 +244,7 @@ class SageForwardEngine:
         m, other = self.model, self.other
         agg = m._aggs[layer][t]
         last = layer == self.n_hops - 1
-        segs = []
-        for (s, h, side, r0, n) in self.segments[t]:
-            if h > self.n_hops - 1 - layer:
-                continue
-            if layer == 0:
-                segs.append({'head_ids': self._slot_ids(self.seeds_buf, h, side),
-                             'child_ids': self._slot_ids(self.seeds_buf, h + 1, side),
-                             'n_heads': n, 'n_child': self.fanouts[h]})
-            else:
-                _, c0, _cn = self.where[s + 2]
-                segs.append({'n_heads': n, 'n_child': self.fanouts[h], 'self_row0': r0, 'child_row0': c0})
+        segs = self._layer_segments(layer, t)
         if layer == 0:
             (f_self, o_self), (f_neigh, o_neigh) = self.tables[t], self.tables[other[t]]
         else:
@@ -239,9 +252,38 @@ class SageForwardEngine:
         normalize = last and m.normalize == "l2"
         out = self.emb[t] if last else self.h[layer][t]
         call = kernels.FusedLayerCall(f_self, o_self, f_neigh, o_neigh, segs, agg.w_self, agg.w_neigh, agg.bias,
-                                      agg.activation, normalize, out)
+                                      agg.activation, normalize, out,
+                                      sampling=self._sampling_desc() if layer == 0 else None)
         self._fused_calls[key] = call
         return call
+
+    def _sampling_desc(self):
+        if not self.draw_deepest:
+            return None
+        return {'indptr': self.indptr, 'indices': self.indices, 'err_flag': self.err_flag,
+                'tape_len': sum(self.sizes[1:])}
+
+    def _layer_segments(self, layer, t):
+        """Segment table of the fused kernel of (layer, head type ``t``): layer 0 addresses feature
+        rows by node id, later layers the previous layer's output rows.  The deepest heads' children
+        are drawn in the kernel when ``draw_deepest``."""
+        segs = []
+        for (s, h, side, r0, n) in self.segments[t]:
+            if h > self.n_hops - 1 - layer:
+                continue
+            if layer == 0:
+                sg = {'head_ids': self._slot_ids(self.seeds_buf, h, side), 'n_heads': n, 'n_child': self.fanouts[h]}
+                if self.draw_deepest and h == self.n_hops - 1:
+                    sg['draw'] = {'hop': h, 'heads_per_walk': self.sizes[h], 'tape_off': sum(self.sizes[1:h + 1]),
+                                  'walk0': side * self.batch,
+                                  'out_child_ids': self._slot_ids(self.seeds_buf, h + 1, side) if self.keep_ids else None}
+                else:
+                    sg['child_ids'] = self._slot_ids(self.seeds_buf, h + 1, side)
+                segs.append(sg)
+            else:
+                _, c0, _cn = self.where[s + 2]
+                segs.append({'n_heads': n, 'n_child': self.fanouts[h], 'self_row0': r0, 'child_row0': c0})
+        return segs
 
     def _run_fused_layer(self, layer, seeds):
         for t in _TYPES:
@@ -253,7 +295,11 @@ class SageForwardEngine:
                         call.set_head_ids(i, self._slot_ids(seeds, 0, side))
             if self.probes is not None and layer == 0:
                 self._arm_probe()
-            call.run()
+            if layer == 0 and self.draw_deepest:
+                rng_seed, walk_ids, replay = self._step_keys
+                call.run(rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
+            else:
+                call.run()
 
     def aggregate_fused(self, seeds):
         """Same result as ``aggregate`` with one kernel per (layer, node type)."""

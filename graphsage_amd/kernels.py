@@ -438,11 +438,17 @@ def fused_supported(fs, fn, h, max_child):
 
 
 class FusedLayerCall:
-    """A prepared ``gs_sage_fused_fwd`` call: segment table and argument checks
-    are done once, ``run()`` only enqueues the kernel."""
+    """A prepared ``gs_sage_fused_fwd`` / ``gs_sage_fused_sampled_fwd`` call: segment
+    table and argument checks are done once, ``run()`` only enqueues the kernel.
+
+    ``sampling`` = {'indptr', 'indices', 'err_flag', 'tape_len'} switches to the
+    entry point that draws children inside the kernel; a segment that is to be
+    drawn carries 'draw' = {'hop', 'heads_per_walk', 'tape_off', 'walk0',
+    'out_child_ids' (optional)} instead of 'child_ids'.  The key, walk ids and tape
+    of a step are arguments of ``run``."""
 
     def __init__(self, feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_neigh, bias, act,
-                 normalize, out, save_self=None, save_mean=None):
+                 normalize, out, save_self=None, save_mean=None, sampling=None):
         lib = load()
         _dev(feat_self, torch.float32, 'feat_self', 2)
         _dev(feat_neigh, torch.float32, 'feat_neigh', 2)
@@ -471,6 +477,16 @@ class FusedLayerCall:
                 if child_ids.numel() != n_heads * n_child:
                     raise ValueError("segment %d: child_ids has %d entries, %d needed" %
                                      (i, child_ids.numel(), n_heads * n_child))
+            if sg.get('draw') is not None:
+                if sampling is None or head_ids is None or child_ids is not None:
+                    raise ValueError("segment %d: a drawn segment needs `sampling`, head ids and no child ids" % i)
+                ids_out = sg['draw'].get('out_child_ids')
+                if ids_out is not None:
+                    _dev(ids_out, torch.int32, 'out_child_ids')
+                    if ids_out.numel() != n_heads * n_child:
+                        raise ValueError("segment %d: out_child_ids has %d entries, %d needed" %
+                                         (i, ids_out.numel(), n_heads * n_child))
+                    self._keep.append(ids_out)
             arr[i] = _lib.FusedSegment(ptr(head_ids), ptr(child_ids), n_heads, int(sg.get('self_row0', 0)),
                                        int(sg.get('child_row0', 0)), n_child)
             self._keep += [head_ids, child_ids]
@@ -491,6 +507,25 @@ class FusedLayerCall:
         self._live_heads = {}
         self._keep += [feat_self, feat_neigh, w_self, w_neigh, bias, out, save_self, save_mean]
         self._weights = (w_self, w_neigh, bias)
+        self._sampling = None
+        if sampling is not None:
+            for name, dtype in (('indptr', torch.int64), ('indices', torch.int32), ('err_flag', torch.int32)):
+                _dev(sampling[name], dtype, name, 1)
+            self._draws = (_lib.FusedDraw * len(segments))()
+            self._walks = 0
+            for i, sg in enumerate(segments):
+                d = sg.get('draw')
+                if d is None:
+                    self._draws[i] = _lib.FusedDraw(-1, 1, 0, 0, None)
+                    continue
+                hpw, walk0 = int(d['heads_per_walk']), int(d['walk0'])
+                if int(sg['n_heads']) % hpw:
+                    raise ValueError("segment %d: %d heads are not whole walks of %d" % (i, int(sg['n_heads']), hpw))
+                self._walks = max(self._walks, walk0 + int(sg['n_heads']) // hpw)
+                self._draws[i] = _lib.FusedDraw(int(d['hop']), hpw, int(d['tape_off']), walk0, ptr(d.get('out_child_ids')))
+            self._sampling = sampling
+            self._tape_len = int(sampling['tape_len'])
+            self._keep += [sampling['indptr'], sampling['indices'], sampling['err_flag']]
         self._head = (ptr(feat_self), feat_self.shape[0], fs, int(off_self), ptr(feat_neigh), feat_neigh.shape[0],
                       fn, int(off_neigh), arr, len(segments))
         self._tail = (2 * hh, ACT[act], int(bool(normalize)), ptr(out), ptr(save_self), ptr(save_mean))
@@ -509,10 +544,26 @@ class FusedLayerCall:
         self._arr[seg].head_ids = head_ids.data_ptr()
         self._live_heads[seg] = head_ids
 
-    def run(self):
+    def run(self, rng_seed=0, walk_id_base=0, walk_ids=None, replay=None):
         if self._epoch != _storage_epoch:
             self._read_weight_addresses()
-        check(self._lib.gs_sage_fused_fwd(*self._args, stream_handle()), 'gs_sage_fused_fwd')
+        if self._sampling is None:
+            check(self._lib.gs_sage_fused_fwd(*self._args, stream_handle()), 'gs_sage_fused_fwd')
+            return self.out
+        sp = self._sampling
+        if walk_ids is not None:
+            _dev(walk_ids, torch.int64, 'walk_ids', 1)
+            if walk_ids.numel() < self._walks:
+                raise ValueError("walk_ids has %d entries, the drawn segments span %d walks" % (walk_ids.numel(), self._walks))
+        if replay is not None:
+            _dev(replay, torch.int32, 'replay', 1)
+            if replay.numel() < self._walks * self._tape_len:
+                raise ValueError("replay tape has %d words, %d needed" % (replay.numel(), self._walks * self._tape_len))
+        desc = _lib.FusedSampling(ptr(sp['indptr']), ptr(sp['indices']), sp['indptr'].numel() - 1,
+                                  int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(walk_id_base) & 0xFFFFFFFFFFFFFFFF,
+                                  ptr(walk_ids), ptr(replay), self._tape_len, ptr(sp['err_flag']))
+        check(self._lib.gs_sage_fused_sampled_fwd(*self._args, ctypes.byref(desc), self._draws, stream_handle()),
+              'gs_sage_fused_sampled_fwd')
         return self.out
 
 

@@ -93,17 +93,7 @@ class SageTrainEngine(SageForwardEngine):
         agg = m._aggs[layer][t]
         last = layer == self.n_hops - 1
         rows = self.h[layer][t].shape[0]
-        segs = []
-        for (s, h, side, r0, n) in self.segments[t]:
-            if h > self.n_hops - 1 - layer:
-                continue
-            if layer == 0:
-                segs.append({'head_ids': self._slot_ids(self.seeds_buf, h, side),
-                             'child_ids': self._slot_ids(self.seeds_buf, h + 1, side),
-                             'n_heads': n, 'n_child': self.fanouts[h]})
-            else:
-                _, c0, _cn = self.where[s + 2]
-                segs.append({'n_heads': n, 'n_child': self.fanouts[h], 'self_row0': r0, 'child_row0': c0})
+        segs = self._layer_segments(layer, t)
         if layer == 0:
             (f_self, o_self), (f_neigh, o_neigh) = self.tables[t], self.tables[other[t]]
             save_self = self.x_self[t]
@@ -113,7 +103,8 @@ class SageTrainEngine(SageForwardEngine):
         out = self.z[t] if last else self.h[layer][t]
         call = kernels.FusedLayerCall(f_self, o_self, f_neigh, o_neigh, segs, agg.w_self, agg.w_neigh, agg.bias,
                                       agg.activation, False, out, save_self=save_self,
-                                      save_mean=self.x_mean[layer][t][:rows])
+                                      save_mean=self.x_mean[layer][t][:rows],
+                                      sampling=self._sampling_desc() if layer == 0 else None)
         self._train_calls[key] = call
         return call
 
@@ -137,7 +128,10 @@ class SageTrainEngine(SageForwardEngine):
                     for i, (_, h, side, _, _) in enumerate(self.segments[t]):
                         if h == 0:
                             call.set_head_ids(i, self._slot_ids(seeds, 0, side))
-                call.run()
+                if layer == 0 and self.draw_deepest:
+                    call.run(rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
+                else:
+                    call.run()
         for t in _TYPES:
             if self.model.normalize == "l2":
                 kernels.l2_normalize(self.z[t], out=self.emb[t])

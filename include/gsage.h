@@ -286,6 +286,57 @@ int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64
                       float *out, float *save_self, float *save_mean, void *stream);
 
 /*
+ * gs_sage_fused_fwd with the children of some segments DRAWN inside the kernel
+ * instead of read from child_ids: the deepest hop of a walk holds most of its
+ * samples (1250 of 1525 for fan-outs 25/10/5), and drawing them where their
+ * feature rows are gathered saves the sampler's pass over them, the id round trip
+ * through memory, and hides the draws' two dependent reads behind the gathers of
+ * other wavefronts.  The draws are exactly those of gs_sample (sampler.py:65-90,
+ * same CSR reads, same Philox counter (walk, hop, slot) or tape word, same
+ * err_flag convention), so gs_sample over hops 0..L-2 followed by this call gives
+ * the ids gs_sample over hops 0..L-1 gives.
+ *   sampling  the adjacency and keys, as the arguments of the same names of
+ *             gs_sample; tape_len = words of replay tape per walk (sum of the hop
+ *             sizes), only read when replay != NULL
+ *   draws     HOST array of n_segs entries.  hop < 0: the segment reads child_ids
+ *             as in gs_sage_fused_fwd.  hop >= 0: head p of the segment is node
+ *             head_ids[p] (required), it belongs to walk walk0 + p / heads_per_walk
+ *             (an index into walk_ids / an offset from walk_id_base / a row of the
+ *             tape) and is slot j = p % heads_per_walk of that walk's hop `hop`-1
+ *             (the root for hop 0); its child c is the draw for slot j * n_child + c
+ *             of hop `hop`, tape word replay[walk * tape_len + tape_off + slot].
+ *             out_child_ids (nullable) receives the drawn ids [n_heads * n_child].
+ * Narrow layers only (the wide-layer kernel reads ids): GS_ELIMIT otherwise.
+ */
+typedef struct gs_fused_sampling {
+    const int64_t *indptr;
+    const int32_t *indices;
+    int64_t n_nodes;
+    uint64_t rng_seed;
+    uint64_t walk_id_base;
+    const int64_t *walk_ids;
+    const uint32_t *replay;
+    int64_t tape_len;
+    int32_t *err_flag;
+} gs_fused_sampling;
+
+typedef struct gs_fused_draw {
+    int32_t hop;
+    int32_t heads_per_walk;
+    int32_t tape_off;
+    int64_t walk0;
+    int32_t *out_child_ids;
+} gs_fused_draw;
+
+int gs_sage_fused_sampled_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
+                              const float *feat_neigh, int64_t n_rows_neigh, int Fn, int64_t off_neigh,
+                              const gs_fused_segment *segs, int n_segs,
+                              const float *W_self, const float *W_neigh, const float *bias,
+                              int H, int act, int normalize,
+                              float *out, float *save_self, float *save_mean,
+                              const gs_fused_sampling *sampling, const gs_fused_draw *draws, void *stream);
+
+/*
  * The whole two-hop forward pass in one kernel, one wavefront per walk: sampling
  * (as gs_sample), both aggregator layers (as gs_sage_fused_fwd) and the l2
  * normalisation, for the reference's own model depth (its generator and type

@@ -72,7 +72,7 @@ def test_one_kernel_forward_agrees_with_layered_path_and_oracle_subset(big, cuda
     walk_ids = torch.cat([2 * torch.arange(B, 2 * B, dtype=torch.int64, device=cuda),
                           2 * torch.arange(B, 2 * B, dtype=torch.int64, device=cuda) + 1])
     eng_w = SageForwardEngine(g, model, B)
-    eng_l = SageForwardEngine(g, model, B, walk_kernel=False)
+    eng_l = SageForwardEngine(g, model, B, walk_kernel=False, keep_ids=True, draw_in_layer=True)
     eng_u = SageForwardEngine(g, model, B, use_fused=False)
     assert eng_w.walk_kernel and all(eng_l.fused_layers)
     out_w = [x.clone() for x in eng_w.forward(seeds, walk_ids, rng_seed=SEED)]

@@ -638,7 +638,8 @@ def test_engine_fused_and_unfused_match_model_and_oracle(cuda, ns, sizes, fu, fi
     seeds = torch.tensor([l[0] for l in links] + [l[1] for l in links], dtype=torch.int32, device=cuda)
     walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda)
 
-    eng_f = SageForwardEngine(g, model, b, use_fused=True, walk_kernel=False)
+    # keep_ids: the layer-0 kernel draws the deepest hop itself and also leaves its ids in hops[-1]
+    eng_f = SageForwardEngine(g, model, b, use_fused=True, walk_kernel=False, keep_ids=True, draw_in_layer=True)
     eng_u = SageForwardEngine(g, model, b, use_fused=False)
     fused_shapes = fu % 32 == 0 and fi % 32 == 0
     assert all(eng_f.fused_layers) == fused_shapes
@@ -709,6 +710,103 @@ def test_walk_kernel_replay_against_reference_batches(golden, cuda, case):
     close(emb[b:], want[1], scale=1.0)
 
 
+@pytest.mark.parametrize('case', [0, 1, 2, 3, 4, 5, 6])
+def test_layer_kernel_draws_replay_against_reference_batches(golden, cuda, case):
+    """gs_sample over all hops but the last + gs_sage_fused_sampled_fwd drawing the last hop inside the
+    layer-0 kernel, on the reference's replayed tapes: the ids the kernel drew equal the reference's
+    walks bit for bit (its hop-2 lists), embeddings equal the float64 oracle applied to the reference
+    generator's own feature arrays."""
+    from graphsage_amd.engine import SageForwardEngine
+    arrays, meta = golden
+    info = meta['replay'][case]
+    key, ns, b = info['key'], info['num_samples'], info['batch']
+    feats, nodes, edges = golden_graph_parts(arrays, info['graph'])
+    pad = lambda a, f: np.concatenate([a, np.zeros((a.shape[0], f - a.shape[1]), np.float32)], axis=1)
+    feats = {'user': pad(feats['user'], 32), 'item': pad(feats['item'], 32)}
+    g = ga.Graph(feats, nodes, edges)
+    links = arrays[key + '_links']
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=1)
+    model = ga.GraphSAGE([32, 32], gen, seed=13).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.1, 0.1)
+    eng = SageForwardEngine(g, model, b, walk_kernel=False, keep_ids=True, draw_in_layer=True)
+    assert eng.draw_deepest and all(eng.fused_layers)
+    seeds = torch.from_numpy(np.concatenate([links[:, 0], links[:, 1]]).astype(np.int32)).to(cuda)
+    tape = torch.from_numpy(arrays[key + '_tape'].view(np.int32)).to(cuda)
+    eng.hops[1].fill_(-5)                                          # the sampler kernel must not be what fills it
+    emb = eng.forward(seeds, replay=tape)
+    assert eng.err_flag.tolist() == [0, 0]
+    np.testing.assert_array_equal(eng.hops[0].cpu().numpy(), arrays[key + '_hop1'])
+    np.testing.assert_array_equal(eng.hops[1].cpu().numpy(), arrays[key + '_hop2'])
+    xin = [torch.from_numpy(pad(arrays[key + '_x%d' % i].reshape(-1, arrays[key + '_x%d' % i].shape[2]), 32)
+                            .reshape(b, -1, 32)).double() for i in range(6)]
+    plan = omodel.LayerPlan([32, 32], ns, g.node_feature_sizes)
+    want = omodel.forward(plan, _oracle_model(model, plan), xin)
+    close(emb[0], want[0], scale=1.0)
+    close(emb[1], want[1], scale=1.0)
+    # without keep_ids nothing is written there and the embeddings are the same bits
+    eng2 = SageForwardEngine(g, model, b, walk_kernel=False, draw_in_layer=True)
+    eng2.hops[1].fill_(-5)
+    emb2 = eng2.forward(seeds, replay=tape)
+    assert torch.equal(emb2[0], emb[0]) and torch.equal(emb2[1], emb[1])
+    assert bool((eng2.hops[1] == -5).all())
+    # and the sampler kernel drawing every hop gives the same embeddings
+    eng3 = SageForwardEngine(g, model, b, walk_kernel=False, draw_in_layer=False)
+    assert not eng3.draw_deepest
+    emb3 = eng3.forward(seeds, replay=tape)
+    assert torch.equal(emb3[0], emb[0]) and torch.equal(emb3[1], emb[1])
+    np.testing.assert_array_equal(eng3.hops[1].cpu().numpy(), arrays[key + '_hop2'])
+
+
+@pytest.mark.parametrize('ns', [[4, 3, 2], [7], [3, 2, 2, 2], [25, 10, 5]])
+def test_layer_kernel_draws_equal_the_sampler_kernel_at_any_depth(golden, cuda, ns):
+    """Philox mode, depths 1 to 4, walk ids beyond 32 bits: the ids drawn inside the layer-0 kernel are
+    the ones gs_sample draws for that hop, and a node without neighbors at the last-but-one hop is
+    reported through err_flag with -1 children, as gs_sample does."""
+    from graphsage_amd.engine import SageForwardEngine
+    arrays, _ = golden
+    feats, nodes, edges = golden_graph_parts(arrays, 'g_mid')
+    pad = lambda a, f: np.concatenate([a, np.zeros((a.shape[0], f - a.shape[1]), np.float32)], axis=1)
+    feats = {'user': pad(feats['user'], 32), 'item': pad(feats['item'], 32)}
+    g = ga.Graph(feats, nodes, edges)
+    b = 19
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=1)
+    model = ga.GraphSAGE([32] * len(ns), gen, seed=13).build()
+    nu = feats['user'].shape[0]
+    half = edges.shape[1] // 2
+    seeds = torch.from_numpy(np.concatenate([edges[0, :b], edges[1, :b]]).astype(np.int32)).to(cuda)
+    assert int(seeds[:b].max()) < nu <= int(seeds[b:].min()) and half >= b
+    walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda) * 5 + (1 << 40)
+    eng = SageForwardEngine(g, model, b, keep_ids=True, walk_kernel=False, draw_in_layer=True)
+    assert eng.draw_deepest
+    emb = [x.clone() for x in eng.forward(seeds, walk_ids, rng_seed=0xABCDEF0123)]
+    dev = g.device_tensors()
+    hops, err = kernels.sample(dev['indptr'], dev['indices'], seeds, ns, rng_seed=0xABCDEF0123, walk_ids=walk_ids)
+    assert err.tolist() == [0, 0] and eng.err_flag.tolist() == [0, 0]
+    for a, c in zip(eng.hops, hops):
+        assert torch.equal(a, c)
+    ref = SageForwardEngine(g, model, b, use_fused=False)
+    out = ref.forward(seeds, walk_ids, rng_seed=0xABCDEF0123)
+    for k in range(2):
+        close(emb[k], out[k], scale=1.0)
+    if len(ns) >= 2:
+        # cut one hop-(L-2) node's adjacency row to nothing: an isolated parent at the drawn hop
+        indptr = dev['indptr'].clone()
+        victim = int(eng.hops[-2][0, 0])
+        lo, hi = int(indptr[victim]), int(indptr[victim + 1])
+        indptr[victim + 1:] -= (hi - lo)
+        indices = torch.cat([dev['indices'][:lo], dev['indices'][hi:]]).contiguous()
+        g2 = ga.Graph.from_csr({'user': dev['user'], 'item': dev['item']}, indptr, indices)
+        eng_i = SageForwardEngine(g2, model, b, keep_ids=True, walk_kernel=False, draw_in_layer=True)
+        eng_i.forward(seeds, walk_ids, rng_seed=0xABCDEF0123)
+        hops_i, err_i = kernels.sample(indptr, indices, seeds, ns, rng_seed=0xABCDEF0123, walk_ids=walk_ids)
+        assert err_i.tolist()[0] >= 1 and eng_i.err_flag.tolist() == err_i.tolist()
+        for a, c in zip(eng_i.hops, hops_i):
+            assert torch.equal(a, c)
+        assert bool((eng_i.hops[-1] == -1).any())
+
+
 @pytest.mark.parametrize('ns,sizes,fu,fi', [([25, 10], [32, 32], 64, 64), ([8, 4], [64, 64], 64, 64),
                                             ([10, 5], [32, 32], 64, 32), ([33, 7], [32, 32], 128, 128),
                                             ([64, 3], [32, 64], 64, 64), ([3, 70], [32, 32], 32, 32),
@@ -733,7 +831,7 @@ def test_walk_kernel_matches_layered_engine_and_oracle(cuda, ns, sizes, fu, fi):
     seeds = torch.tensor([l[0] for l in links] + [l[1] for l in links], dtype=torch.int32, device=cuda)
     walk_ids = (torch.arange(2 * b, dtype=torch.int64, device=cuda) * 3 + (1 << 35))
     eng_w = SageForwardEngine(g, model, b)
-    eng_l = SageForwardEngine(g, model, b, walk_kernel=False)
+    eng_l = SageForwardEngine(g, model, b, walk_kernel=False, keep_ids=True, draw_in_layer=True)
     assert eng_w.walk_kernel and not eng_l.walk_kernel
     out_w = [x.clone() for x in eng_w.forward(seeds, walk_ids, rng_seed=4242)]
     out_l = [x.clone() for x in eng_l.forward(seeds, walk_ids, rng_seed=4242)]
