@@ -80,7 +80,8 @@ SIGNATURES['gs_sage_fused_sampled_fwd'] = (_i32, [_vp, _i64, _i32, _i64, _vp, _i
 class WgradProblem(_c.Structure):
     """gs_wgrad_problem of include/gsage.h."""
     _fields_ = [('x_self', _vp), ('x_mean', _vp), ('out', _vp), ('g_out', _vp), ('g_W_self', _vp), ('g_W_neigh', _vp),
-                ('g_bias', _vp), ('workspace', _vp), ('workspace_bytes', _sz)]
+                ('g_bias', _vp), ('workspace', _vp), ('workspace_bytes', _sz),
+                ('self_ids', _vp), ('self_off', _i64), ('self_rows', _i64)]
 
 
 SIGNATURES['gs_sage_project_wgrad_pair'] = (_i32, [_c.POINTER(WgradProblem), _c.POINTER(WgradProblem),
@@ -93,7 +94,8 @@ class SageWeights(_c.Structure):
 
 class Sage2Saved(_c.Structure):
     """gs_sage2_saved of include/gsage.h."""
-    _fields_ = [('x_self', _vp * 2), ('x_mean', _vp * 2), ('h1', _vp * 2), ('x_mean1', _vp * 2), ('z', _vp * 2)]
+    _fields_ = [('x_self', _vp * 2), ('x_mean', _vp * 2), ('h1', _vp * 2), ('x_mean1', _vp * 2), ('z', _vp * 2),
+                ('self_ids', _vp * 2)]
 
 
 SIGNATURES['gs_sage2_supported'] = (_i32, [_i32] * 6)
@@ -105,6 +107,12 @@ SIGNATURES['gs_sage2_forward'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _
 SIGNATURES['gs_sage2_backward_tail'] = (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
                                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 
+SIGNATURES['gs_sage_project_wgrad_by_id_supported'] = (_i32, [_i32, _i32, _i32])
+SIGNATURES['gs_sage2_tail_head_workspace'] = (_sz, [_i64, _i32])
+SIGNATURES['gs_sage2_tail_head_rows'] = (_i32, [_i64])
+SIGNATURES['gs_sage2_backward_tail_head'] = (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
+                                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp])
+SIGNATURES['gs_link_head_reduce'] = (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp])
 _f32 = _c.c_float
 SIGNATURES['gs_link_head_workspace'] = (_sz, [_i64, _i32])
 SIGNATURES['gs_link_head_fwd'] = (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp])

@@ -186,6 +186,15 @@ extern "C" int gs_link_head_mse_fwd_bwd(const float *emb_user, const float *emb_
     return gs::check_launch("gs_link_head_mse_fwd_bwd (reduce)");
 }
 
+extern "C" int gs_link_head_reduce(const void *slab, int n_rows, int E, int64_t B, float *g_kernel, float *g_bias,
+                                   float *loss, void *stream) {
+    if (n_rows < 1 || E < 1 || B < 1) return gs::fail(GS_EINVAL, "gs_link_head_reduce: n_rows=%d E=%d B=%lld", n_rows, E, (long long)B);
+    if (!slab || !g_kernel || !g_bias || !loss) return gs::fail(GS_EINVAL, "gs_link_head_reduce: null pointer argument");
+    hipLaunchKernelGGL(link_head_reduce_kernel, dim3((unsigned)((2 * E + 2 + 15) / 16)), dim3(kThreads), 0, (hipStream_t)stream,
+                       static_cast<const float *>(slab), n_rows, 2 * E, 1.f / (float)B, g_kernel, g_bias, loss);
+    return gs::check_launch("gs_link_head_reduce");
+}
+
 // ---- the same step for callers that cannot allocate ---------------------------------------
 // The slab of per-block partial sums lives in device memory that belongs to the library's code
 // object: every GPU the library runs on holds its own copy at its own address until the process

@@ -770,6 +770,10 @@ constexpr int WD_UNROLL = 4;            // MFMA steps (of four rows) whose loads
 struct WgradDirectSide {
     const float *Xs, *Xn, *G, *Mk;
     float *slab_s, *slab_n;
+    // ids != NULL: row m of the own-row operand is row ids[m] - off of the table Xs (rows outside
+    // [0, rows) count as zeros), so the forward pass need not keep a gathered copy of those rows
+    const int32_t *ids;
+    long long off, rows;
 };
 
 // blockIdx.y picks the instance: the two node types of a layer have the same shapes, and one launch
@@ -785,6 +789,8 @@ void wgrad_direct_kernel(const WgradDirectSide p0, const WgradDirectSide p1, int
     const float *__restrict__ Mk = second ? p1.Mk : p0.Mk;
     float *__restrict__ slab_s = second ? p1.slab_s : p0.slab_s;
     float *__restrict__ slab_n = second ? p1.slab_n : p0.slab_n;
+    const int32_t *__restrict__ ids = second ? p1.ids : p0.ids;
+    const long long id_off = second ? p1.off : p0.off, id_rows = second ? p1.rows : p0.rows;
     constexpr int kSlabS = (KS + 1) * HH, kSlabN = (KN + 1) * HH;
     __shared__ float red[kSlabS + kSlabN];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -806,16 +812,39 @@ void wgrad_direct_kernel(const WgradDirectSide p0, const WgradDirectSide p1, int
         for (int t = 0; t < VN; ++t) acc_n[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // ids of the rows of an iteration are fetched one iteration ahead (a dependent read otherwise)
+    int32_t idc[WD_UNROLL];
+#pragma unroll
+    for (int u = 0; u < WD_UNROLL; ++u) {
+        idc[u] = 0;
+        if (ids && w_begin < w_end) idc[u] = ids[min(w_begin + 4 * u + q, w_end - 1)];
+    }
     for (int64_t m0 = w_begin; m0 < w_end; m0 += 4 * WD_UNROLL) {
         XVec<VS> xs[WD_UNROLL];
         XVec<VN> xn[WD_UNROLL];
         float gs_[WD_UNROLL][NT], gn_[WD_UNROLL][NT];
+        int32_t idn[WD_UNROLL];
+#pragma unroll
+        for (int u = 0; u < WD_UNROLL; ++u) {
+            idn[u] = 0;
+            if (ids) idn[u] = ids[min(m0 + 4 * WD_UNROLL + 4 * u + q, w_end - 1)];
+        }
 #pragma unroll
         for (int u = 0; u < WD_UNROLL; ++u) {
             const int64_t m = m0 + 4 * u + q;
             const bool live = m < w_end;
             const int64_t mc = live ? m : w_end - 1;            // a row past the range is read in place, weight 0
-            xs[u].load(Xs + mc * KS + VS * r);
+            if (ids) {
+                const long long row = (long long)idc[u] - id_off;
+                const bool ok = (unsigned long long)row < (unsigned long long)id_rows;
+                xs[u].load(Xs + (ok ? row : 0) * KS + VS * r);
+                if (!ok) {
+#pragma unroll
+                    for (int t = 0; t < VS; ++t) xs[u].v[t] = 0.f;
+                }
+            } else {
+                xs[u].load(Xs + mc * KS + VS * r);
+            }
             xn[u].load(Xn + mc * KN + VN * r);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -842,6 +871,8 @@ void wgrad_direct_kernel(const WgradDirectSide p0, const WgradDirectSide p1, int
                 bias_n[nt] += gn_[u][nt];
             }
         }
+#pragma unroll
+        for (int u = 0; u < WD_UNROLL; ++u) idc[u] = idn[u];
     }
     // column sums: the four row classes (q) of a column, added in q order
 #pragma unroll
@@ -1080,7 +1111,7 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
             const int64_t rpb = wgrad_direct_rows(M);
             const int64_t nblocks = (M + rpb - 1) / rpb;          // <= nc: the slabs fit the workspace
             slab1 = slab0 + (size_t)nblocks * (Fs + 1) * Hh;
-            const WgradDirectSide side{x_self, x_mean, g_out, mask, slab0, slab1};
+            const WgradDirectSide side{x_self, x_mean, g_out, mask, slab0, slab1, nullptr, 0, 0};
             direct = launch_wgrad_direct(Fs, Fn, Hh, side, side, 1, M, rpb, nblocks, s);
             if (direct) {
                 if (int rc = gs::check_launch("gs_sage_project_bwd (wgrad)")) return rc;
@@ -1141,6 +1172,10 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
     return GS_OK;
 }
 
+extern "C" int gs_sage_project_wgrad_by_id_supported(int Fs, int Fn, int H) {
+    return (H % 2 == 0) && wgrad_direct_covers(Fs, Fn, H / 2) && !(Fs % 128 == 0 && Fn % 128 == 0 && (H / 2) % 128 == 0);
+}
+
 // Weight and bias gradients of two projections of one shape (the two node types of a layer) with one
 // weight-gradient launch and one reduction launch; falls back to two gs_sage_project_bwd calls when
 // the shape has no direct kernel.
@@ -1162,9 +1197,14 @@ extern "C" int gs_sage_project_wgrad_pair(const gs_wgrad_problem *a, const gs_wg
                             need, p.workspace_bytes, i);
         const float *mask = act == GS_ACT_RELU ? p.out : nullptr;
         direct = direct && aligned16(p.x_self) && aligned16(p.x_mean) && aligned16(p.g_out) && (!mask || aligned16(mask));
+        if (p.self_ids && p.self_rows < 1)
+            return gs::fail(GS_EINVAL, "gs_sage_project_wgrad_pair: problem %d gives self_ids but self_rows=%lld", i, (long long)p.self_rows);
     }
     if (M == 0) return GS_OK;
     if (!direct) {
+        if (a->self_ids || b->self_ids)
+            return gs::fail(GS_ELIMIT, "gs_sage_project_wgrad_pair: own rows by id need a shape of the direct kernel "
+                                       "(gs_sage_project_wgrad_by_id_supported); Fs=%d Fn=%d H=%d is not one", Fs, Fn, H);
         for (int i = 0; i < 2; ++i) {
             const gs_wgrad_problem &p = *pr[i];
             // (no input gradients are asked for, so the weights are not read)
@@ -1185,7 +1225,8 @@ extern "C" int gs_sage_project_wgrad_pair(const gs_wgrad_problem *a, const gs_wg
         const gs_wgrad_problem &p = *pr[i];
         float *slab0 = static_cast<float *>(p.workspace);
         float *slab1 = slab0 + (size_t)nblocks * (Fs + 1) * Hh;
-        sd[i] = WgradDirectSide{p.x_self, p.x_mean, p.g_out, act == GS_ACT_RELU ? p.out : nullptr, slab0, slab1};
+        sd[i] = WgradDirectSide{p.x_self, p.x_mean, p.g_out, act == GS_ACT_RELU ? p.out : nullptr, slab0, slab1,
+                                p.self_ids, (long long)p.self_off, (long long)p.self_rows};
         rs.s[2 * i] = ReduceSide{slab0, p.g_W_self, p.g_bias, Fs};
         rs.s[2 * i + 1] = ReduceSide{slab1, p.g_W_neigh, p.g_bias ? p.g_bias + Hh : nullptr, Fn};
     }

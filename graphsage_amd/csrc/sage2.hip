@@ -60,6 +60,7 @@ struct Sage2Args {
     // n_pairs + p*n0 + j hop-1 head j of the walk rooted at the other type's root of pair p.
     float *sv_x_self[2], *sv_x_mean[2], *sv_h1[2];
     float *sv_x_mean1[2], *sv_z[2];                   // n_pairs rows: layer-1 neighbor mean, pre-norm output
+    int32_t *sv_self_ids[2];                          // same rows as sv_x_self: the node id instead of its feature row
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -220,6 +221,8 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             if (!live) v = -1;
             hop1[t] = v;
             if (a.out_hop1) a.out_hop1[(size_t)w * n0 + t] = v;
+            if (SAVE && a.sv_self_ids[1 - side])              // row of hop-1 head t in the other type's tables
+                a.sv_self_ids[1 - side][a.n_pairs + (w - (side ? a.n_pairs : 0)) * n0 + t] = v;
         }
     }
     wave_lds_fence();
@@ -342,7 +345,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         for (int pass = 0; pass < NPASS_O; ++pass) {
             const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
             *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = own[pass];
-            if (SAVE && rr < np)
+            if (SAVE && a.sv_x_self[1 - side] && rr < np)
                 stream_store(a.sv_x_self[1 - side] + (size_t)(sv_h1row + j0 + rr) * FO + 4 * c, own[pass]);
             rootsum.x += own[pass].x; rootsum.y += own[pass].y; rootsum.z += own[pass].z; rootsum.w += own[pass].w;
         }
@@ -381,7 +384,8 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
             if (SAVE) stream_store(a.sv_x_mean[side] + (size_t)pair * FO + 4 * lane, mean);
         }
-        if (SAVE && lane < FTV) stream_store(a.sv_x_self[side] + (size_t)pair * FT + 4 * lane, own_root);
+        if (SAVE && a.sv_x_self[side] && lane < FTV) stream_store(a.sv_x_self[side] + (size_t)pair * FT + 4 * lane, own_root);
+        if (SAVE && a.sv_self_ids[side] && lane == 0) a.sv_self_ids[side][pair] = root;
         wave_lds_fence();
         f32x4 acc_s[NT1], acc_n[NT1];
 #pragma unroll
@@ -637,8 +641,9 @@ extern "C" int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, i
     a.h1_rows = 1 + n0;
     if (saved) {
         for (int t = 0; t < 2; ++t) {
-            if (!saved->x_self[t] || !saved->x_mean[t] || !saved->h1[t] || !saved->x_mean1[t] || !saved->z[t])
+            if ((!saved->x_self[t] && !saved->self_ids[t]) || !saved->x_mean[t] || !saved->h1[t] || !saved->x_mean1[t] || !saved->z[t])
                 return gs::fail(GS_EINVAL, "gs_sage2_forward: saved-activation set has a null pointer");
+            a.sv_self_ids[t] = saved->self_ids[t];
             if (!aligned16(saved->x_self[t]) || !aligned16(saved->x_mean[t]) || !aligned16(saved->h1[t]) ||
                 !aligned16(saved->x_mean1[t]))
                 return gs::fail(GS_EINVAL, "gs_sage2_forward: saved-activation buffers must be 16-byte aligned");

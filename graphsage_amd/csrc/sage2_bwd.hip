@@ -31,6 +31,9 @@ struct TailArgs {
     float *g_z[2], *g_h1[2];
     long long n_pairs;
     int n0, H1, H2, normalize, relu;
+    // HEAD: the link head and its loss in the same launch (g_emb is then not read)
+    const float *emb[2], *head_kernel, *head_bias, *targets;
+    float *pred, *head_slab;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -45,7 +48,15 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int H1, int HH2>
+// HEAD: the gradient of the embeddings is not an input but comes from the link head evaluated here,
+// pred = sigmoid(<concat(user_emb, item_emb), kernel> + bias) with the mean-squared-error loss
+// (link_utils.py:167-168,244-247; train_movielens.py:186): both walks of a pair evaluate the pair's
+// score (two 64-byte rows), the walk of type t takes g_emb[t] = gz * kernel[t half] from it and adds
+// gz * emb[t] to its lane's partial sum of the kernel gradient's t half; the user-side walk also
+// owns the pair's prediction, its share of the loss and of the bias gradient.  A block leaves its
+// partial sums as one slab row [2E kernel | bias | loss] (waves added in wave order), and
+// gs_link_head_reduce adds the rows in block order.
+template <int H1, int HH2, bool HEAD>
 __global__ __launch_bounds__(kThreads)
 void sage2_tail_bwd_kernel(const TailArgs a) {
     extern __shared__ float smem[];
@@ -57,13 +68,21 @@ void sage2_tail_bwd_kernel(const TailArgs a) {
     const long long w_first = (long long)blockIdx.x * kWaves + wave, w_step = (long long)gridDim.x * kWaves;
 
     // the first walk's rows are requested before the weights, so that the two round trips overlap
-    float zc = 0.f, gc = 0.f;
+    float zc = 0.f, gc = 0.f, eu = 0.f, ei = 0.f, yt = 0.f;
     if (w_first < walks && lane < H2) {
         const int t = w_first >= a.n_pairs;
         const long long p = w_first - (t ? a.n_pairs : 0);
         zc = a.z[t][p * H2 + lane];
-        gc = a.g_emb[t][p * H2 + lane];
+        if (HEAD) { eu = a.emb[0][p * H2 + lane]; ei = a.emb[1][p * H2 + lane]; yt = a.targets[p]; }
+        else gc = a.g_emb[t][p * H2 + lane];
     }
+    float hk_u = 0.f, hk_i = 0.f, hb = 0.f;                       // head: kernel (this lane's column of both halves), bias
+    float acc_ku = 0.f, acc_ki = 0.f, acc_b = 0.f, acc_l = 0.f;   // head: this wave's partial gradient sums and loss
+    if (HEAD) {
+        if (lane < H2) { hk_u = a.head_kernel[lane]; hk_i = a.head_kernel[H2 + lane]; }
+        hb = a.head_bias[0];
+    }
+    const float inv_b = 1.f / (float)a.n_pairs;
     for (int i = threadIdx.x; i < 4 * wsz; i += kThreads) {
         const int m = i / wsz, e = i - m * wsz;                   // e = k * HH2 + n: the weights are read in memory order
         const int k = e / HH2, n = e - k * HH2;
@@ -78,8 +97,26 @@ void sage2_tail_bwd_kernel(const TailArgs a) {
         const int t = w >= a.n_pairs, o = 1 - t;
         const long long p = w - (t ? a.n_pairs : 0);
         if (w != w_first) {
-            zc = gc = 0.f;
-            if (lane < H2) { zc = a.z[t][p * H2 + lane]; gc = a.g_emb[t][p * H2 + lane]; }
+            zc = gc = eu = ei = 0.f;
+            if (lane < H2) {
+                zc = a.z[t][p * H2 + lane];
+                if (HEAD) { eu = a.emb[0][p * H2 + lane]; ei = a.emb[1][p * H2 + lane]; yt = a.targets[p]; }
+                else gc = a.g_emb[t][p * H2 + lane];
+            }
+        }
+        if (HEAD) {
+            const float zh = wave_sum(eu * hk_u + ei * hk_i) + hb;
+            const float pr = 1.f / (1.f + __expf(-zh));
+            const float d = pr - yt;
+            const float gzh = 2.f * d * inv_b * pr * (1.f - pr);
+            gc = gzh * (t ? hk_i : hk_u);
+            if (t) acc_ki += gzh * ei;
+            else {
+                acc_ku += gzh * eu;
+                acc_b += gzh;
+                acc_l += d * d;
+                if (lane == 0) a.pred[p] = pr;
+            }
         }
         float gz = gc;
         if (a.normalize) {
@@ -111,6 +148,40 @@ void sage2_tail_bwd_kernel(const TailArgs a) {
         for (int i = lane; i < span4; i += 64) dst[i] = v4;
         wave_lds_fence();                                         // gz_s is rewritten by the next walk
     }
+    if (HEAD) {
+        // block slab row: columns [0, H2) kernel gradient user half, [H2, 2 H2) item half, then bias, loss
+        __syncthreads();                                          // all waves are done with the staged weights
+        float *red = smem;                                        // [kWaves][2 * H2 + 2] over the weight area
+        constexpr int C = 2 * H2 + 2;
+        if (lane < H2) { red[wave * C + lane] = acc_ku; red[wave * C + H2 + lane] = acc_ki; }
+        if (lane == 0) { red[wave * C + 2 * H2] = acc_b; red[wave * C + 2 * H2 + 1] = acc_l; }
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < kWaves; ++wv) s += red[wv * C + threadIdx.x];
+            a.head_slab[(size_t)blockIdx.x * C + threadIdx.x] = s;
+        }
+    }
+}
+
+inline int64_t tail_blocks(int64_t n_pairs) {
+    int64_t blocks = (2 * n_pairs + kWaves - 1) / kWaves;
+    return blocks > 512 ? 512 : blocks;
+}
+
+int launch_tail(const TailArgs &a, bool head, hipStream_t s) {
+    const int64_t blocks = tail_blocks(a.n_pairs);
+    const int H1 = a.H1, H2 = a.H2;
+    const size_t lds = (size_t)(4 * (H2 / 2) * H1 + kWaves * kMaxH) * sizeof(float);        // at most 36 KB
+#define GS_TAIL(h1, hh2) \
+    if (H1 == h1 && H2 == 2 * hh2) { \
+        if (head) hipLaunchKernelGGL((sage2_tail_bwd_kernel<h1, hh2, true>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a); \
+        else hipLaunchKernelGGL((sage2_tail_bwd_kernel<h1, hh2, false>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a); \
+    }
+    GS_TAIL(32, 16) GS_TAIL(32, 32) GS_TAIL(64, 16) GS_TAIL(64, 32)
+#undef GS_TAIL
+    return gs::check_launch(head ? "gs_sage2_backward_tail_head" : "gs_sage2_backward_tail");
 }
 
 }  // namespace
@@ -138,13 +209,44 @@ extern "C" int gs_sage2_backward_tail(const float *z_user, const float *z_item,
     a.w_self[0] = w1_self_user; a.w_neigh[0] = w1_neigh_user; a.w_self[1] = w1_self_item; a.w_neigh[1] = w1_neigh_item;
     a.g_z[0] = g_z_user; a.g_z[1] = g_z_item; a.g_h1[0] = g_h1_user; a.g_h1[1] = g_h1_item;
     a.n_pairs = n_pairs; a.n0 = n0; a.H1 = H1; a.H2 = H2; a.normalize = normalize != 0; a.relu = act == GS_ACT_RELU;
-    int64_t blocks = (2 * n_pairs + kWaves - 1) / kWaves;
-    if (blocks > 512) blocks = 512;
-    const size_t lds = (size_t)(4 * (H2 / 2) * H1 + kWaves * kMaxH) * sizeof(float);        // at most 36 KB
-    hipStream_t s = (hipStream_t)stream;
-    if (H1 == 32 && H2 == 32) hipLaunchKernelGGL((sage2_tail_bwd_kernel<32, 16>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a);
-    else if (H1 == 32) hipLaunchKernelGGL((sage2_tail_bwd_kernel<32, 32>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a);
-    else if (H2 == 32) hipLaunchKernelGGL((sage2_tail_bwd_kernel<64, 16>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a);
-    else hipLaunchKernelGGL((sage2_tail_bwd_kernel<64, 32>), dim3((unsigned)blocks), dim3(kThreads), lds, s, a);
-    return gs::check_launch("gs_sage2_backward_tail");
+    return launch_tail(a, false, (hipStream_t)stream);
+}
+
+extern "C" size_t gs_sage2_tail_head_workspace(int64_t n_pairs, int H2) {
+    if (n_pairs < 0 || H2 < 1) return 0;
+    return (size_t)tail_blocks(n_pairs) * (size_t)(2 * H2 + 2) * sizeof(float);
+}
+
+extern "C" int gs_sage2_tail_head_rows(int64_t n_pairs) { return (int)tail_blocks(n_pairs); }
+
+extern "C" int gs_sage2_backward_tail_head(const float *z_user, const float *z_item,
+                                           const float *emb_user, const float *emb_item, const float *targets,
+                                           const float *head_kernel, const float *head_bias,
+                                           int64_t n_pairs, int n0, int H1, int H2, int normalize, int act,
+                                           const float *w1_self_user, const float *w1_neigh_user,
+                                           const float *w1_self_item, const float *w1_neigh_item,
+                                           float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
+                                           float *pred, void *head_slab, size_t head_slab_bytes, void *stream) {
+    if (n_pairs < 1 || n0 < 1) return gs::fail(GS_EINVAL, "gs_sage2_backward_tail_head: n_pairs=%lld n0=%d", (long long)n_pairs, n0);
+    if ((H1 != 32 && H1 != 64) || (H2 != 32 && H2 != 64))
+        return gs::fail(GS_ELIMIT, "gs_sage2_backward_tail_head: H1=%d H2=%d (each 32 or 64: the widths of gs_sage2_forward)", H1, H2);
+    if (act != GS_ACT_LINEAR && act != GS_ACT_RELU) return gs::fail(GS_EINVAL, "gs_sage2_backward_tail_head: unknown activation %d", act);
+    if (!z_user || !z_item || !emb_user || !emb_item || !targets || !head_kernel || !head_bias || !w1_self_user ||
+        !w1_neigh_user || !w1_self_item || !w1_neigh_item || !g_z_user || !g_z_item || !g_h1_user || !g_h1_item ||
+        !pred || !head_slab)
+        return gs::fail(GS_EINVAL, "gs_sage2_backward_tail_head: null pointer argument");
+    if ((reinterpret_cast<uintptr_t>(g_h1_user) | reinterpret_cast<uintptr_t>(g_h1_item)) & 15)
+        return gs::fail(GS_EINVAL, "gs_sage2_backward_tail_head: g_h1 tables must be 16-byte aligned");
+    if (n_pairs > ((int64_t)1 << 40) / (1 + n0)) return gs::fail(GS_ELIMIT, "gs_sage2_backward_tail_head: n_pairs=%lld too large", (long long)n_pairs);
+    const size_t need = gs_sage2_tail_head_workspace(n_pairs, H2);
+    if (head_slab_bytes < need)
+        return gs::fail(GS_EINVAL, "gs_sage2_backward_tail_head: workspace of %zu bytes needed, %zu given", need, head_slab_bytes);
+    TailArgs a{};
+    a.z[0] = z_user; a.z[1] = z_item;
+    a.w_self[0] = w1_self_user; a.w_neigh[0] = w1_neigh_user; a.w_self[1] = w1_self_item; a.w_neigh[1] = w1_neigh_item;
+    a.g_z[0] = g_z_user; a.g_z[1] = g_z_item; a.g_h1[0] = g_h1_user; a.g_h1[1] = g_h1_item;
+    a.n_pairs = n_pairs; a.n0 = n0; a.H1 = H1; a.H2 = H2; a.normalize = normalize != 0; a.relu = act == GS_ACT_RELU;
+    a.emb[0] = emb_user; a.emb[1] = emb_item; a.head_kernel = head_kernel; a.head_bias = head_bias; a.targets = targets;
+    a.pred = pred; a.head_slab = static_cast<float *>(head_slab);
+    return launch_tail(a, true, (hipStream_t)stream);
 }

@@ -363,22 +363,35 @@ class WgradPairCall:
     """A prepared ``gs_sage_project_wgrad_pair`` call: weight and bias gradients of
     two projections of one shape (the two node types of a layer), checked once,
     enqueued by ``run()``.  Each problem is a dict with x_self, x_mean, out (or
-    None), g_out, g_w_self, g_w_neigh, g_bias (or None), workspace."""
+    None), g_out, g_w_self, g_w_neigh, g_bias (or None), workspace.  With
+    'self_ids' (int32 [M]) and 'self_off' in a problem, its x_self is the feature
+    TABLE and the own rows are read from it by id."""
 
     def __init__(self, problems, act):
         lib = load()
         if len(problems) != 2:
             raise ValueError("two problems expected")
-        m, fs = problems[0]['x_self'].shape
+        m, fs = problems[0]['x_mean'].shape[0], problems[0]['x_self'].shape[1]
         fn = problems[0]['x_mean'].shape[1]
         h = problems[0]['g_out'].shape[1]
         need = lib.gs_sage_project_bwd_workspace(fs, fn, h, m)
         self._keep, self._structs = [], []
         for p in problems:
+            by_id = p.get('self_ids') is not None
+            if by_id:
+                _dev(p['self_ids'], torch.int32, 'self_ids', 1)
+                if p['self_ids'].numel() != m:
+                    raise ValueError("self_ids has %d entries, %d needed" % (p['self_ids'].numel(), m))
+                if not lib.gs_sage_project_wgrad_by_id_supported(fs, fn, h):
+                    raise _lib.GsageError("own rows by id are not available for Fs=%d Fn=%d H=%d" % (fs, fn, h))
             for name, shape in (('x_self', (m, fs)), ('x_mean', (m, fn)), ('g_out', (m, h)), ('out', (m, h))):
                 if p.get(name) is None and name == 'out':
                     continue
                 _dev(p[name], torch.float32, name, 2)
+                if by_id and name == 'x_self':
+                    if p[name].shape[1] != fs:
+                        raise ValueError("the feature table must be %d wide" % fs)
+                    continue
                 if tuple(p[name].shape) != shape:
                     raise ValueError("%s must be %s (got %s)" % (name, shape, tuple(p[name].shape)))
             for name, n in (('g_w_self', fs * (h // 2)), ('g_w_neigh', fn * (h // 2)), ('g_bias', h)):
@@ -395,7 +408,9 @@ class WgradPairCall:
             self._keep.append(dict(p))
             self._structs.append(_lib.WgradProblem(ptr(p['x_self']), ptr(p['x_mean']), ptr(p.get('out')), ptr(p['g_out']),
                                                    ptr(p['g_w_self']), ptr(p['g_w_neigh']), ptr(p.get('g_bias')),
-                                                   ptr(p['workspace']), p['workspace'].numel() * 4))
+                                                   ptr(p['workspace']), p['workspace'].numel() * 4,
+                                                   ptr(p.get('self_ids')), int(p.get('self_off', 0)),
+                                                   p['x_self'].shape[0] if by_id else 0))
         self._args = (fs, fn, m, h, ACT[act])
         self._lib = lib
         self.epoch = _storage_epoch            # the gradient views it writes belong to this parameter layout
@@ -427,6 +442,56 @@ def sage2_backward_tail(z, g_emb, w1_self, w1_neigh, n0, normalize, act, g_z, g_
                                      ptr(w1_self['user']), ptr(w1_neigh['user']), ptr(w1_self['item']), ptr(w1_neigh['item']),
                                      ptr(g_z['user']), ptr(g_z['item']), ptr(g_h1['user']), ptr(g_h1['item']),
                                      stream_handle()), 'gs_sage2_backward_tail')
+
+
+def sage2_backward_tail_head(z, emb, targets, head_kernel, head_bias, w1_self, w1_neigh, n0, normalize, act,
+                             g_z, g_h1, pred, slab):
+    """``gs_sage2_backward_tail_head``: ``sage2_backward_tail`` with the link head and its
+    loss inside; ``emb`` = {'user','item'} embeddings (B, H2), ``slab`` the float32 workspace
+    that ``link_head_reduce`` turns into the head's gradients and the loss."""
+    lib = load()
+    types = ('user', 'item')
+    b, h2 = z['user'].shape
+    h1 = w1_self['user'].shape[0]
+    for t in types:
+        for name, d, shape in (('z', z, (b, h2)), ('emb', emb, (b, h2)), ('g_z', g_z, (b, h2)),
+                               ('w1_self', w1_self, (h1, h2 // 2)), ('w1_neigh', w1_neigh, (h1, h2 // 2)),
+                               ('g_h1', g_h1, (b * (1 + int(n0)), h1))):
+            _dev(d[t], torch.float32, '%s[%s]' % (name, t), 2)
+            if tuple(d[t].shape) != shape:
+                raise ValueError("%s[%s] must be %s (got %s)" % (name, t, shape, tuple(d[t].shape)))
+    for name, t, n in (('targets', targets, b), ('pred', pred, b), ('head_kernel', head_kernel, 2 * h2), ('head_bias', head_bias, 1)):
+        _dev(t, torch.float32, name)
+        if t.numel() != n:
+            raise ValueError("%s must have %d elements (got %d)" % (name, n, t.numel()))
+    _dev(slab, torch.float32, 'slab', 1)
+    check(lib.gs_sage2_backward_tail_head(ptr(z['user']), ptr(z['item']), ptr(emb['user']), ptr(emb['item']), ptr(targets),
+                                          ptr(head_kernel), ptr(head_bias), b, int(n0), h1, h2, int(bool(normalize)), ACT[act],
+                                          ptr(w1_self['user']), ptr(w1_neigh['user']), ptr(w1_self['item']), ptr(w1_neigh['item']),
+                                          ptr(g_z['user']), ptr(g_z['item']), ptr(g_h1['user']), ptr(g_h1['item']),
+                                          ptr(pred), ptr(slab), slab.numel() * 4, stream_handle()),
+          'gs_sage2_backward_tail_head')
+
+
+def tail_head_slab(b, h2, device):
+    """Workspace of ``sage2_backward_tail_head`` for B pairs and H2-wide embeddings."""
+    n = load().gs_sage2_tail_head_workspace(int(b), int(h2))
+    return torch.empty(max(n // 4, 1), dtype=torch.float32, device=device)
+
+
+def link_head_reduce(slab, b, e, g_kernel, g_bias, loss):
+    """Adds the slab rows of ``sage2_backward_tail_head`` into the head's gradients and the loss."""
+    lib = load()
+    _dev(slab, torch.float32, 'slab', 1)
+    for name, t, n in (('g_kernel', g_kernel, 2 * e), ('g_bias', g_bias, 1), ('loss', loss, 1)):
+        _dev(t, torch.float32, name)
+        if t.numel() != n:
+            raise ValueError("%s must have %d elements" % (name, n))
+    rows = lib.gs_sage2_tail_head_rows(int(b))
+    if slab.numel() < rows * (2 * e + 2):
+        raise ValueError("slab too small")
+    check(lib.gs_link_head_reduce(ptr(slab), rows, int(e), int(b), ptr(g_kernel), ptr(g_bias), ptr(loss), stream_handle()),
+          'gs_link_head_reduce')
 
 
 def sage2_backward_tail_supported(h1, h2):
@@ -642,6 +707,14 @@ class Sage2Call:
                       'h1': lambda t: (rows, h1), 'x_mean1': lambda t: (self.n_pairs, h1),
                       'z': lambda t: (self.n_pairs, h2)}
             st = _lib.Sage2Saved()
+            if saved.get('self_ids') is not None:          # node ids instead of the gathered own rows
+                for i, t in enumerate(('user', 'item')):
+                    buf = saved['self_ids'][t]
+                    _dev(buf, torch.int32, 'saved[self_ids][%s]' % t, 1)
+                    if buf.numel() != rows:
+                        raise ValueError("saved[self_ids][%s] must have %d entries" % (t, rows))
+                    st.self_ids[i] = buf.data_ptr()
+                shapes.pop('x_self')
             for name, shape in shapes.items():
                 for i, t in enumerate(('user', 'item')):
                     buf = saved[name][t]

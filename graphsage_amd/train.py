@@ -227,10 +227,24 @@ class Trainer:
         self._prepare_head_step()
         # every gradient of the bucket is overwritten by this step's kernels: no zeroing pass
         emb_u, emb_i = eng.forward_train(seeds, walk_ids, rng_seed)
-        loss, pred = self._head_step.run(emb_u, emb_i, targets)
-        eng.backward(self._head_step.g_user, self._head_step.g_item)
+        loss, pred = self._head_and_backward(emb_u, emb_i, targets)
         self.opt.step(grad_scale=self.bucket.all_reduce_sum(self.group))
         return loss, pred.reshape(-1, 1)
+
+    def _head_and_backward(self, emb_u, emb_i, targets):
+        """Head + loss + the engine's backward pass; on the two-hop route the head is evaluated inside
+        the first kernel of the backward pass instead of two launches of its own."""
+        eng, hs = self.engine, self._head_step
+        if eng.tail_kernel:
+            if not (isinstance(targets, torch.Tensor) and targets.is_cuda and targets.dtype == torch.float32
+                    and targets.is_contiguous() and targets.numel() == eng.batch):
+                raise ValueError("targets must be a contiguous float32 GPU tensor of %d entries" % eng.batch)
+            eng.backward_head(self.head.kernel, self.head.bias, targets, self.head.kernel.grad, self.head.bias.grad,
+                              hs.pred, hs.loss)
+            return hs.loss, hs.pred
+        loss, pred = hs.run(emb_u, emb_i, targets)
+        eng.backward(hs.g_user, hs.g_item)
+        return loss, pred
 
     def _prepare_head_step(self):
         """(Re)builds the prepared head call and drops the engine's prepared weight-gradient calls when the
@@ -255,8 +269,7 @@ class Trainer:
         from . import kernels
         eng = self.engine
         emb_u, emb_i = eng.forward_train(eng.seeds_buf, self._walk_buf, self._graph_seed)
-        self._head_step.run(emb_u, emb_i, self._target_buf)
-        eng.backward(self._head_step.g_user, self._head_step.g_item)
+        self._head_and_backward(emb_u, emb_i, self._target_buf)
         if with_update:
             kernels.adam_step(self.opt.p_flat, self.opt.g, self.opt.m, self.opt.v, 0.0, self.opt.b1, self.opt.b2,
                               self.opt.eps, lr_t_device=self.opt.lr_dev)

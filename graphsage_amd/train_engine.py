@@ -66,9 +66,31 @@ class SageTrainEngine(SageForwardEngine):
         self._side = None                                       # second stream of the backward pass
         self._walk_train_call = None
         # ... and then the top of the backward pass in one kernel as well (see _backward_walks)
-        self.tail_kernel = self.walk_train and kernels.sage2_backward_tail_supported(m.dims[1]['user'], m.dims[2]['user'])
+        self._tail_kernel = self.walk_train and kernels.sage2_backward_tail_supported(m.dims[1]['user'], m.dims[2]['user'])
         self._side2 = None
         self._wgrad_pairs = None
+        # Own rows of layer 0 are not written by the forward pass when the weight-gradient kernel can read
+        # them from the feature table by node id: the forward kernel then leaves 4 bytes per row (the id)
+        # instead of the row.
+        self.self_ids = None
+        if (self._tail_kernel and f['user'] == f['item'] and
+                kernels.load().gs_sage_project_wgrad_by_id_supported(f['user'], f['item'], m.dims[1]['user'])):
+            self.self_ids = {t: torch.zeros(self.h[0][t].shape[0], dtype=torch.int32, device=dev) for t in _TYPES}
+        self._head_slab = None
+
+    @property
+    def tail_kernel(self):
+        return self._tail_kernel
+
+    @tail_kernel.setter
+    def tail_kernel(self, on):
+        """Switching the one-launch top of the backward pass off (comparisons, tests) also brings back
+        the gathered copy of the own rows, which the layer-by-layer backward kernels read."""
+        self._tail_kernel = bool(on) and self.walk_train
+        if not self._tail_kernel and self.self_ids is not None:
+            self.self_ids = None
+            self._walk_train_call = None
+            self._wgrad_pairs = None
 
     def _forward_walks_train(self, seeds, walk_ids, rng_seed, replay):
         m = self.model
@@ -78,6 +100,9 @@ class SageTrainEngine(SageForwardEngine):
             rows = {t: self.h[0][t].shape[0] for t in _TYPES}
             saved = {'x_self': self.x_self, 'x_mean': {t: self.x_mean[0][t][:rows[t]] for t in _TYPES},
                      'h1': self.h[0], 'x_mean1': {t: self.x_mean[1][t][:self.batch] for t in _TYPES}, 'z': self.z}
+            if self.self_ids is not None:
+                saved['self_ids'] = self.self_ids
+                del saved['x_self']
             self._walk_train_call = kernels.Sage2Call(
                 self.indptr, self.indices, self.tables['user'][0], self.tables['item'][0], self.fanouts, weights,
                 m.normalize == "l2", self.batch, emb=self.emb_all, saved=saved)
@@ -166,7 +191,19 @@ class SageTrainEngine(SageForwardEngine):
         return self.g_xs[layer][t]
 
     # ---- backward -----------------------------------------------------------------
-    def _backward_walks(self, g_user, g_item, main):
+    def backward_head(self, head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss):
+        """The link head (concat -> Dense(1, sigmoid), mean squared error against ``targets``) and the
+        whole backward pass from the embeddings ``forward_train`` left in the engine: the head is
+        evaluated inside the kernel that starts the backward pass, its parameter gradients and the loss
+        are summed beside the weight gradients.  Only when ``tail_kernel``."""
+        if not self.tail_kernel:
+            raise kernels._lib.GsageError("backward_head needs the two-hop one-kernel route")
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._backward_walks(None, None, main, head=(head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss))
+
+    def _backward_walks(self, g_user, g_item, main, head=None):
         """Two hops on the one-kernel forward's tables: one launch takes the embedding
         gradients through the l2 normalisation, the layer-1 input gradients and the
         neighbor-mean broadcast for both node types; after it only weight gradients
@@ -179,9 +216,19 @@ class SageTrainEngine(SageForwardEngine):
         if self._side2 is None:
             self._side2 = torch.cuda.Stream()
         top = m._aggs[1]
-        kernels.sage2_backward_tail(self.z, {'user': g_user.contiguous(), 'item': g_item.contiguous()},
-                                    {t: top[t].w_self for t in _TYPES}, {t: top[t].w_neigh for t in _TYPES},
-                                    self.fanouts[0], m.normalize == "l2", top['user'].activation, self.g_z, self.g_h[0])
+        if head is None:
+            kernels.sage2_backward_tail(self.z, {'user': g_user.contiguous(), 'item': g_item.contiguous()},
+                                        {t: top[t].w_self for t in _TYPES}, {t: top[t].w_neigh for t in _TYPES},
+                                        self.fanouts[0], m.normalize == "l2", top['user'].activation, self.g_z, self.g_h[0])
+        else:
+            head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss = head
+            if self._head_slab is None:
+                self._head_slab = kernels.tail_head_slab(self.batch, m.dims[2]['user'], self.indptr.device)
+            kernels.sage2_backward_tail_head(self.z, {'user': self.emb_all[:self.batch], 'item': self.emb_all[self.batch:]},
+                                             targets, head_kernel, head_bias,
+                                             {t: top[t].w_self for t in _TYPES}, {t: top[t].w_neigh for t in _TYPES},
+                                             self.fanouts[0], m.normalize == "l2", top['user'].activation,
+                                             self.g_z, self.g_h[0], pred, self._head_slab)
         f = {t: self.x_self[t].shape[1] for t in _TYPES}
         if f['user'] == f['item']:
             # both node types of a layer have one shape: each layer's weight gradients are one launch (+ one
@@ -191,11 +238,16 @@ class SageTrainEngine(SageForwardEngine):
             self._side2.wait_stream(main)
             self._wgrad_pairs[0].run()
             with torch.cuda.stream(self._side2):
+                if head is not None:                        # the head's slab rows, beside the weight gradients
+                    kernels.link_head_reduce(self._head_slab, self.batch, m.dims[2]['user'], g_kernel, g_bias, loss)
                 self._wgrad_pairs[1].run()
             main.wait_stream(self._side2)
         else:
             self._side.wait_stream(main)
             self._side2.wait_stream(main)
+            if head is not None:
+                with torch.cuda.stream(self._side2):
+                    kernels.link_head_reduce(self._head_slab, self.batch, m.dims[2]['user'], g_kernel, g_bias, loss)
             for t, stream in (('user', main), ('item', self._side)):
                 with torch.cuda.stream(stream):
                     self._weight_grads(0, t)
@@ -235,8 +287,11 @@ class SageTrainEngine(SageForwardEngine):
             agg = self.model._aggs[layer][t]
             x_self, x_mean, out, g_out = self._wgrad_inputs(layer, t)
             g_ws, g_wn, g_b = self._grads_of(agg)
-            problems.append({'x_self': x_self, 'x_mean': x_mean, 'out': out, 'g_out': g_out, 'g_w_self': g_ws,
-                             'g_w_neigh': g_wn, 'g_bias': g_b, 'workspace': self.ws[layer][t]})
+            prob = {'x_self': x_self, 'x_mean': x_mean, 'out': out, 'g_out': g_out, 'g_w_self': g_ws,
+                    'g_w_neigh': g_wn, 'g_bias': g_b, 'workspace': self.ws[layer][t]}
+            if layer == 0 and self.self_ids is not None:    # own rows from the feature table, by the saved ids
+                prob.update(x_self=self.tables[t][0], self_ids=self.self_ids[t], self_off=self.tables[t][1])
+            problems.append(prob)
         return kernels.WgradPairCall(problems, self.model._aggs[layer]['user'].activation)
 
     def backward(self, g_user, g_item):

@@ -219,6 +219,12 @@ int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_mean, int Fn
  * stream for them.  Each problem brings its own workspace of
  * gs_sage_project_bwd_workspace(Fs, Fn, H, M) bytes.  out is the forward output
  * (read for the relu mask, may be NULL for a linear layer); g_bias may be NULL.
+ * self_ids != NULL: the own rows are not given as a gathered [M, Fs] copy; x_self
+ * is then the feature table [self_rows, Fs] itself and row m of the operand is its
+ * row self_ids[m] - self_off (an id outside the table counts as a row of zeros,
+ * as in gs_sage_project_gather_fwd), so the forward pass of a training step need
+ * not write those rows anywhere.  Only for the shapes for which
+ * gs_sage_project_wgrad_by_id_supported() != 0 (GS_ELIMIT otherwise).
  */
 typedef struct gs_wgrad_problem {
     const float *x_self, *x_mean;   /* [M, Fs], [M, Fn]  */
@@ -227,8 +233,11 @@ typedef struct gs_wgrad_problem {
     float *g_bias;                  /* [H] or NULL       */
     void *workspace;
     size_t workspace_bytes;
+    const int32_t *self_ids;        /* [M] or NULL       */
+    int64_t self_off, self_rows;
 } gs_wgrad_problem;
 
+int gs_sage_project_wgrad_by_id_supported(int Fs, int Fn, int H);
 int gs_sage_project_wgrad_pair(const gs_wgrad_problem *a, const gs_wgrad_problem *b,
                                int Fs, int Fn, int64_t M, int H, int act, void *stream);
 
@@ -373,11 +382,13 @@ typedef struct gs_sage_weights {
 } gs_sage_weights;
 
 typedef struct gs_sage2_saved {
-    float *x_self[2];
+    float *x_self[2];       /* may be NULL when self_ids is given */
     float *x_mean[2];
     float *h1[2];
     float *x_mean1[2];
     float *z[2];
+    int32_t *self_ids[2];   /* nullable: [rows] the node id of each row of x_self (4 bytes instead of a feature row;
+                               gs_sage_project_wgrad_pair reads the rows from the table by these ids) */
 } gs_sage2_saved;
 
 int gs_sage2_supported(int Fu, int Fi, int H1, int H2, int n0, int n1);
@@ -419,6 +430,32 @@ int gs_sage2_backward_tail(const float *z_user, const float *z_item,
                            const float *w1_self_item, const float *w1_neigh_item,
                            float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
                            void *stream);
+
+/*
+ * gs_sage2_backward_tail with the link head and its loss evaluated in the same
+ * launch (link_utils.py:167-168,244-247; MSE of train_movielens.py:186): instead
+ * of reading g_emb it takes the embeddings emb_user / emb_item [n_pairs, H2] (the
+ * output of gs_sage2_forward), the head's kernel [2 H2] and bias [1] and targets
+ * [n_pairs], writes pred [n_pairs] and uses the head's own gradient at the
+ * embeddings.  The head's parameter gradients and the loss leave the launch as
+ * per-block partial sums in head_slab (gs_sage2_tail_head_workspace bytes,
+ * gs_sage2_tail_head_rows rows of 2 H2 + 2 floats: kernel gradient, bias
+ * gradient, sum of squared errors); gs_link_head_reduce adds them in row order
+ * into g_kernel [2 H2], g_bias [1] and loss [1] (= sum / B) -- bitwise
+ * reproducible, and off the critical path of the rest of the backward pass.
+ */
+size_t gs_sage2_tail_head_workspace(int64_t n_pairs, int H2);
+int gs_sage2_tail_head_rows(int64_t n_pairs);
+int gs_sage2_backward_tail_head(const float *z_user, const float *z_item,
+                                const float *emb_user, const float *emb_item, const float *targets,
+                                const float *head_kernel, const float *head_bias,
+                                int64_t n_pairs, int n0, int H1, int H2, int normalize, int act,
+                                const float *w1_self_user, const float *w1_neigh_user,
+                                const float *w1_self_item, const float *w1_neigh_item,
+                                float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
+                                float *pred, void *head_slab, size_t head_slab_bytes, void *stream);
+int gs_link_head_reduce(const void *slab, int n_rows, int E, int64_t B, float *g_kernel, float *g_bias,
+                        float *loss, void *stream);
 
 /*
  * Link head of the reference's training script: concat(user_emb, item_emb) ->
