@@ -187,6 +187,10 @@ struct Producer {
                 const bool none = key[p][u] == kNoKey;
                 mask |= none ? 1u << (p * CH + u) : 0u;
                 const uint32_t k = none ? 0u : key[p][u];
+#ifdef WIDE_DIAG_NO_GATHER                              // timing aid (-DWIDE_DIAG_NO_GATHER): everything but the row loads
+                s.v[p][u] = f32x4{1.f, 1.f, 1.f, (float)k};
+                continue;
+#endif
                 if (ASYNC) {
                     if (BIG) s.v[p][u] = load16_async(base + (unsigned long long)k * fb + (uint32_t)(a_kq * 16));
                     else s.v[p][u] = load16_async(base, k + (uint32_t)(a_kq * 16));
@@ -462,7 +466,11 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
 #define WD_MFMA_STEP(S_, st_)                                                                       \
     WD_MFMA_ROW(0, a##S_##0, b##S_##st_, st_) WD_MFMA_ROW(1, a##S_##1, b##S_##st_, st_)             \
     WD_MFMA_ROW(2, a##S_##2, b##S_##st_, st_) WD_MFMA_ROW(3, a##S_##3, b##S_##st_, st_)
+#ifdef WIDE_DIAG_NO_MFMA                                    // timing aid (-DWIDE_DIAG_NO_MFMA): everything but the matrix instructions
+#define WD_MFMA(S_) asm volatile("" :: "v"(a##S_##0), "v"(a##S_##1), "v"(a##S_##2), "v"(a##S_##3), "v"(b##S_##0), "v"(b##S_##1), "v"(b##S_##2), "v"(b##S_##3));
+#else
 #define WD_MFMA(S_) WD_MFMA_STEP(S_, 0) WD_MFMA_STEP(S_, 1) WD_MFMA_STEP(S_, 2) WD_MFMA_STEP(S_, 3)
+#endif
 
     // weight slices, for the slice after the one being multiplied: a thread fetches four 16-byte pieces
     // W[k][4c .. 4c+3] of the row-major weight (coalesced: 32 threads cover a 128-column row) and writes
