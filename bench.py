@@ -246,6 +246,28 @@ def result_line(args, cfg, engine, world, b, fwd, train, cpu, ranks_seen=1):
     dom_avg = sum(dom_ms) / max(len(dom_ms), 1) * 1e-3
     dom_bytes = engine.dominant_bytes()
     achieved = dom_bytes / dom_avg / 1e9 if dom_avg > 0 else 0.0
+    traffic = engine.measured_traffic(args.workload)
+    roof = {"bound": "hbm", "kernel": engine.dominant_name(), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "frac": achieved / 8000.0, "traffic": traffic, "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes,
+            "launches_timed": len(dom_ms)}
+    if traffic is not None and traffic < dom_bytes:
+        # Part of the algorithmic bytes never leaves the L2s (hot rows of a skewed graph, rows shared by the walks of a
+        # batch).  Priced per level: what the counters saw at the fabric side at the HBM peak (Infinity-Cache hits are
+        # counted there too, so this flatters nobody), the rest at the aggregate L2 rate (34.5 TB/s).  The launch is
+        # measured against the time both would take back to back.
+        l2_peak = 34500.0
+        t_min = traffic / 8000.0 + (dom_bytes - traffic) / l2_peak            # in units of bytes per (GB/s)
+        cache_peak = dom_bytes / t_min
+        roof["cache_aware"] = {"peak": cache_peak, "frac": achieved / cache_peak, "l2_share": 1.0 - traffic / dom_bytes,
+                               "hbm_side_gbps": traffic / dom_avg / 1e9 if dom_avg > 0 else 0.0,
+                               "note": "peak = bytes / (fabric-side bytes / 8 TB/s + L2-served bytes / 34.5 TB/s)"}
+        if roof["frac"] > 1.0:
+            # algorithmic bytes outrun the HBM peak: the HBM figure is not a bound for this workload, the cache-aware one is
+            roof["bound"] = "hbm+l2"
+            roof["peak"] = cache_peak
+            roof["frac"] = achieved / cache_peak
+    if roof["frac"] > 1.0:
+        roof["bound"] = "cache-assisted (algorithmic bytes outrun the HBM peak; no counter pass is stored for this workload and kernel source)"
     out = {
         "metric": "seed edges/sec (2-hop sample+aggregate fwd)" if len(cfg['fan']) == 2
                   else "seed edges/sec (%d-hop sample+aggregate fwd)" % len(cfg['fan']),
@@ -259,9 +281,7 @@ def result_line(args, cfg, engine, world, b, fwd, train, cpu, ranks_seen=1):
                    "parallelism": "seed-edge data parallel x%d, graph+features replicated" % world},
         "algorithmic_bytes_per_seed_edge": (samp_bytes + agg_bytes) / b,
         "achieved_hbm_gbps_whole_step": (samp_bytes + agg_bytes) / b * value / world / 1e9,
-        "roofline": {"bound": "hbm", "kernel": engine.dominant_name(), "achieved": achieved, "peak": 8000.0,
-                     "unit": "GB/s", "frac": achieved / 8000.0, "traffic": engine.measured_traffic(args.workload),
-                     "launch_us": dom_avg * 1e6, "bytes_per_launch": dom_bytes, "launches_timed": len(dom_ms)},
+        "roofline": roof,
     }
     flops = engine.dominant_flops()
     if flops and dom_avg > 0:

@@ -400,12 +400,16 @@ class SageForwardEngine:
         return sum(per_type) / len(per_type)
 
     def measured_traffic(self, workload):
-        """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes,
+        """HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes,
         if a measurement of this kernel on this workload (graph, batch, fan-outs)
-        was stored under profiles/; None otherwise."""
+        is stored under profiles/ AND was taken on the kernel source that is in the
+        tree now (the entry carries the git blob hash of the kernel's file); None
+        otherwise, so that a stale figure is never printed."""
+        import hashlib
         import json
         import os
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'traffic.json')
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(root, 'profiles', 'traffic.json')
         if not os.path.exists(path):
             return None
         with open(path) as fh:
@@ -415,8 +419,30 @@ class SageForwardEngine:
             name = "sage_wide_kernel"
         if self.walk_kernel:
             name = "sage2_kernel"
-        key = "%s/%s/B%d/%s" % (workload, name, self.batch, 'x'.join(str(n) for n in self.fanouts))
-        return rec.get(key)
+        tail = "/B%d/%s" % (self.batch, 'x'.join(str(n) for n in self.fanouts))
+        # entries are keyed by the kernel's full name, template arguments included
+        if name == "sage_fused_kernel":          # the layer-0 instantiation: <Fs, Fn, H/2, ids, ...>; both node types, averaged
+            f = self.graph.node_feature_sizes
+            hits = [v for k, v in rec.items() if k.endswith(tail) and any(
+                k.startswith("%s/sage_fused_kernel<%d, %d, %d, false" % (workload, f[t], f[self.other[t]], self.model.dims[1][t] // 2))
+                for t in _TYPES)]
+        elif name == "sage2_kernel":             # <Fu, Fi, H1/2, H2/2, buffer loads, SAVING>: the plain forward saves nothing
+            hits = [v for k, v in rec.items() if k.startswith("%s/sage2_kernel<" % workload) and k.endswith("false>" + tail)]
+        else:
+            hits = [v for k, v in rec.items() if k.startswith("%s/%s<" % (workload, name)) and k.endswith(tail)]
+        out = []
+        for entry in hits:
+            if not isinstance(entry, dict):
+                return None                       # an entry without a source hash cannot be trusted
+            for src, want in entry.get('source', {}).items():
+                try:
+                    data = open(os.path.join(root, src), 'rb').read()
+                except OSError:
+                    return None
+                if hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest() != want:
+                    return None                   # the kernel has changed since it was measured
+            out.append(float(entry['bytes']))
+        return sum(out) / len(out) if out else None
 
     # algorithmic bytes of one step, per the accounting used for the roofline
     def algorithmic_bytes(self):

@@ -3,9 +3,21 @@
 profiles/<name>.md: per-kernel time from the kernel trace, and HBM traffic per
 launch of our kernels from the FETCH_SIZE / WRITE_SIZE passes.
 
-gfx950 counter corrections: FETCH_SIZE and WRITE_SIZE are reported in KiB;
-FETCH_SIZE counts 128-byte read requests as 64 bytes for wide coalesced reads, so
-the read side is doubled (upper estimate; narrower accesses are uncalibrated)."""
+gfx950 counter corrections: FETCH_SIZE and WRITE_SIZE are reported in KiB.
+FETCH_SIZE = read requests x 64 bytes; a wide coalesced read (16 bytes per lane)
+travels as 128-byte requests, so for kernels whose reads are such row streams
+(WIDE_READERS below) the read side is doubled.  Kernels that read scattered
+4- or 8-byte words (the sampler, the adjacency build) are NOT doubled: their
+figure is "requests x 64 bytes", the sectors they cost.  A kernel that mixes both
+(the one-kernel forward: rows + its own sampling reads) is doubled as a whole, an
+upper estimate.
+
+    python tools/summarize_profile.py <gpurun_out/prof_dir> <name> [<workload> <batch> <fanouts like 25x10>]
+
+With the last three arguments the dominant kernels' bytes per launch are also
+entered in profiles/traffic.json, each with the git blob hash of the kernel's
+source file, so that a reader of the entry can tell whether it still describes
+the code."""
 import csv
 import glob
 import json
@@ -18,6 +30,23 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ours = ('sage2_kernel', 'sage2_tail_bwd_kernel', 'stage_batch_kernel', 'sage_wide_kernel', 'l2norm_inplace_kernel', 'sage_fused_kernel', 'sample_kernel', 'gather_mean_kernel', 'gather_rows_kernel', 'rows_gemm_kernel',
         'rows_gemm_big_kernel', 'wgrad_big_kernel', 'wgrad_kernel', 'wgrad_direct_kernel', 'wgrad_reduce_kernel', 'l2norm', 'link_head', 'adam_kernel', 'csr_',
         'group_max_bwd_kernel', 'head_')
+
+
+WIDE_READERS = ('sage2_kernel', 'sage_fused_kernel', 'sage_wide_kernel', 'gather_mean_kernel', 'gather_rows_kernel',
+                'rows_gemm', 'wgrad', 'sage2_tail_bwd_kernel', 'link_head', 'adam_kernel', 'l2norm')
+SOURCE_OF = {'sage2_kernel': 'sage2.hip', 'sage_fused_kernel': 'fused.hip', 'sage_wide_kernel': 'wide.hip',
+             'sample_kernel': 'sampler.hip', 'gather_mean_kernel': 'gather.hip'}
+
+
+def fetch_factor(kernel):
+    return 2.0 if any(w in kernel for w in WIDE_READERS) else 1.0
+
+
+def blob_hash(path):
+    """git's blob id of a file (sha1 over 'blob <size>\\0' + content), computed without git."""
+    import hashlib
+    data = open(path, 'rb').read()
+    return hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()
 
 
 def short(n):
@@ -57,13 +86,14 @@ for kind, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
         traffic.setdefault(k, {})[kind] = (sum(v) / len(v) * 1024.0, len(v))
 if traffic:
     lines += ['## HBM-side traffic per launch (rocprofv3 --pmc, separate passes)', '',
-              '| kernel | launches | FETCH_SIZE raw MB | read MB (x2 gfx950 correction) | WRITE_SIZE MB |',
-              '|---|---|---|---|---|']
+              '| kernel | launches | FETCH_SIZE raw MB (requests x 64 B) | factor | read MB | WRITE_SIZE MB |',
+              '|---|---|---|---|---|---|']
     for k, d in sorted(traffic.items()):
         f, nf = d.get('fetch', (0.0, 0))
         w, _ = d.get('write', (0.0, 0))
-        lines.append('| %s | %d | %.2f | %.2f | %.2f |' % (k, nf, f / 1e6, 2 * f / 1e6, w / 1e6))
-    lines.append('')
+        lines.append('| %s | %d | %.2f | x%d | %.2f | %.2f |' % (k, nf, f / 1e6, fetch_factor(k), fetch_factor(k) * f / 1e6, w / 1e6))
+    lines += ['', 'factor x2: 16-byte-per-lane row streams (128-byte requests tallied at 64 bytes); x1: scattered word reads, '
+              'the figure is the sectors they cost.', '']
 sq_files = sorted(glob.glob(os.path.join(src, 'sq', '*', '*counter_collection.csv')), key=os.path.getmtime, reverse=True)
 if sq_files:
     # per kernel: the launch with the most wave cycles (the largest shape of that kernel)
@@ -98,3 +128,22 @@ if stats:
 print('\n'.join(lines))
 json.dump({k: {kk: vv[0] for kk, vv in d.items()} for k, d in traffic.items()},
           open(os.path.join(root, 'profiles', name + '_traffic_raw.json'), 'w'), indent=1)
+
+if len(sys.argv) >= 6:
+    workload, batch, fan = sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    tj = os.path.join(root, 'profiles', 'traffic.json')
+    rec = json.load(open(tj)) if os.path.exists(tj) else {}
+    rec['_comment'] = ("HBM-side bytes per launch of a workload's dominant kernels: FETCH_SIZE x factor + WRITE_SIZE from separate "
+                       "rocprofv3 --pmc passes (tools/summarize_profile.py); 'source' holds the git blob hash of the kernel's "
+                       "file at the time of the measurement")
+    for k, d in traffic.items():
+        base = k.split('<')[0]
+        if base not in SOURCE_OF or 'fetch' not in d:
+            continue
+        src_file = os.path.join('graphsage_amd', 'csrc', SOURCE_OF[base])
+        key = '%s/%s/B%d/%s' % (workload, k, batch, fan)        # k keeps the template arguments: variants stay apart
+        rec[key] = {'bytes': fetch_factor(k) * d['fetch'][0] + d.get('write', (0.0, 0))[0],
+                    'fetch_raw': d['fetch'][0], 'fetch_factor': fetch_factor(k), 'write': d.get('write', (0.0, 0))[0],
+                    'launches': d['fetch'][1], 'source': {src_file: blob_hash(os.path.join(root, src_file))},
+                    'profile': 'profiles/%s.md' % name}
+    json.dump(rec, open(tj, 'w'), indent=1, sort_keys=True)
