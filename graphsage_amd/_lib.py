@@ -28,6 +28,8 @@ SIGNATURES = {
     'gs_timer_destroy': (_i32, [_vp]),
     'gs_sample': (_i32, [_vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32), _i32, _u64, _u64, _vp, _vp,
                          _c.POINTER(_vp), _vp, _vp]),
+    'gs_sample_cyclic': (_i32, [_vp, _vp, _i64, _vp, _i64, _c.POINTER(_c.c_int32), _i32, _vp, _u64, _vp, _vp, _i64,
+                                _c.POINTER(_vp), _vp, _vp]),
     'gs_csr_build_workspace': (_i32, [_i64, _i64, _i64, _c.POINTER(_sz)]),
     'gs_csr_build': (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     'gs_gather_rows': (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp]),

@@ -164,6 +164,24 @@ class Graph(object):
         return {'user': self.node_features['user'].shape[1],
                 'item': self.node_features['item'].shape[1]}
 
+    # ---- cursors of the cyclic walker -----------------------------------------
+    def sampling_cursor(self):
+        """Per-node cursors of the cyclic walker (``sampler_backup.BreadthFirstWalker``) as a GPU
+        tensor int64[num nodes], all zero at first like the reference's ``sampling_index_dict``
+        (``bipartite_graph.py:44-46``)."""
+        if getattr(self, '_cursor', None) is None:
+            import torch
+            dev = self.device_tensors()['indptr'].device
+            self._cursor = torch.zeros(self._num_users + self._num_items, dtype=torch.int64, device=dev)
+        return self._cursor
+
+    @property
+    def sampling_index_dict(self):
+        """The cursors as the reference's attribute of this name presents them: {node: position in its
+        neighbor list} (a snapshot; the walker advances the device copy)."""
+        cur = self.sampling_cursor().cpu().tolist()
+        return {v: cur[v] for v in range(len(cur)) if self._has(v)}
+
     # ---- device residency -------------------------------------------------
     def device_tensors(self):
         """CSR and fp32 feature tables as GPU tensors (uploaded once, then kept:

@@ -136,6 +136,46 @@ def sample(indptr, indices, seeds, fanouts, rng_seed=0, walk_id_base=0, walk_ids
     return hops, err_flag
 
 
+def sample_cyclic(indptr, indices, seeds, fanouts, cursor, state, rng_seed=0, perm_tape=None, err_flag=None,
+                  perm_tape_len=None):
+    """``gs_sample_cyclic``: the reference's cyclic without-replacement walk.  ``cursor`` (int64 [n_nodes])
+    and ``state`` (int64 [2]) are updated in place; returns (per-hop int32 tensors, err_flag)."""
+    lib = load()
+    _dev(indptr, torch.int64, 'indptr', 1)
+    _dev(indices, torch.int32, 'indices', 1)
+    _dev(seeds, torch.int32, 'seeds', 1)
+    _dev(cursor, torch.int64, 'cursor', 1)
+    _dev(state, torch.int64, 'state', 1)
+    fanouts = [int(f) for f in fanouts]
+    if not 1 <= len(fanouts) <= _lib.GS_MAX_HOPS:
+        raise ValueError("between 1 and %d hops are supported" % _lib.GS_MAX_HOPS)
+    if any(f < 1 for f in fanouts):
+        raise ValueError("fan-outs must be positive")
+    n_nodes = indptr.numel() - 1
+    if cursor.numel() != n_nodes or state.numel() != 2:
+        raise ValueError("cursor must have one entry per node and state two entries")
+    if perm_tape is not None:
+        _dev(perm_tape, torch.int32, 'perm_tape', 1)
+        if perm_tape_len is not None and not 0 <= int(perm_tape_len) <= perm_tape.numel():
+            raise ValueError("perm_tape_len outside the tape")
+        if perm_tape.numel() == 0:
+            raise ValueError("an empty tape has no address: pass a one-element tensor and perm_tape_len=0")
+    if err_flag is None:
+        err_flag = torch.zeros(2, dtype=torch.int32, device=seeds.device)
+    else:
+        _dev(err_flag, torch.int32, 'err_flag', 1)
+    n_seeds = seeds.numel()
+    hops = [torch.empty((n_seeds, s), dtype=torch.int32, device=seeds.device) for s in hop_sizes(fanouts)]
+    fan_arr = (ctypes.c_int32 * len(fanouts))(*fanouts)
+    out_arr = (ctypes.c_void_p * len(hops))(*[h.data_ptr() for h in hops])
+    check(lib.gs_sample_cyclic(ptr(indptr), ptr(indices), n_nodes, ptr(seeds), n_seeds, fan_arr, len(fanouts), ptr(cursor),
+                               int(rng_seed) & 0xFFFFFFFFFFFFFFFF, ptr(state), ptr(perm_tape),
+                               0 if perm_tape is None else (perm_tape.numel() if perm_tape_len is None else int(perm_tape_len)),
+                               out_arr, ptr(err_flag), stream_handle()),
+          'gs_sample_cyclic')
+    return hops, err_flag
+
+
 def gather_rows(feat, ids, id_offset=0, out=None):
     lib = load()
     _dev(feat, torch.float32, 'feat', 2)

@@ -118,6 +118,37 @@ int gs_sample(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
               int32_t *const *out_hops, int32_t *err_flag, void *stream);
 
 /*
+ * The reference's alternate walker (backup/sampler_backup.py:47-114): instead of
+ * drawing with replacement, a visit of node v takes the next fanouts[hop] entries
+ * of v's neighbor list starting at a per-node cursor (Graph.sampling_index_dict,
+ * bipartite_graph.py:28,44-46), and when the cursor runs off the end of the list
+ * the rest is taken from the start of a fresh permutation of it
+ * (sampler_backup.py:85-96).  Arguments and output layout as gs_sample, plus
+ *   cursor   device int64[n_nodes], read AND written: the cursors carry over from
+ *            call to call, as the dict does in the reference
+ *   state    device int64[2], read and written: [0] permutations drawn so far (the
+ *            Philox counter of the next one), [1] tape words consumed so far
+ *   perm_tape / perm_tape_len  nullable device int32: replay mode, the index
+ *            permutations the reference's numpy.random.permutation calls returned,
+ *            back to back in call order (entry i of a permutation p of a list x
+ *            means permutation(x)[i] = x[p[i]]); without it permutation t is a
+ *            Feistel network keyed by Philox4x32-10(counter (t, round), rng_seed)
+ *   err_flag [0] as gs_sample (1 + id of a visited node without neighbors: the
+ *            reference raises ValueError, sampler_backup.py:100); [1] = 1 for a root
+ *            outside the graph, 2 when the tape is too short
+ * A cursor depends on every earlier visit of its node, in the reference's visit
+ * order (roots in call order, each walk breadth first), so the visits are
+ * sequential by definition: one wavefront walks them in order.  It reproduces
+ * that sampler; gs_sample is the fast one.
+ */
+int gs_sample_cyclic(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
+                     const int32_t *seeds, int64_t n_seeds,
+                     const int32_t *fanouts, int n_hops,
+                     int64_t *cursor, uint64_t rng_seed, int64_t *state,
+                     const int32_t *perm_tape, int64_t perm_tape_len,
+                     int32_t *const *out_hops, int32_t *err_flag, void *stream);
+
+/*
  * out[i, :] = feat[ids[i] - id_offset, :].
  * Replaces Graph.get_node_features_from_node (bipartite_graph.py:70-76; id_offset
  * is its correction_constant for items, 0 for users) as called from

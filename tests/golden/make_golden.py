@@ -6,8 +6,8 @@ the GPU box does):
 
     python tests/golden/make_golden.py [/root/reference]
 
-What is imported: the reference's ``bipartite_graph.py``, ``sampler.py`` and
-``generator.py``, unmodified.  ``generator.py`` and ``utils.py`` import
+What is imported: the reference's ``bipartite_graph.py``, ``sampler.py``,
+``generator.py`` and ``backup/sampler_backup.py``, unmodified.  ``generator.py`` and ``utils.py`` import
 TensorFlow for two base classes (``Sequence``, ``Layer``) that play no part in
 batching or sampling; TensorFlow is not installed here, so empty stand-in
 classes are registered under those module names before the import.  No
@@ -326,6 +326,71 @@ def sequence_cases(meta):
     meta['sequence'] = out
 
 
+class TapePermutation:
+    """Stands in for the ``numpy.random`` module inside the reference's backup/sampler_backup.py
+    (its ``np_rn``): ``permutation(x)`` applies the next pre-drawn index permutation."""
+
+    def __init__(self, perms):
+        self.perms = perms
+        self.pos = 0
+
+    def permutation(self, x):
+        p = self.perms[self.pos]
+        self.pos += 1
+        assert len(p) == len(x)
+        return np.asarray(x)[p]
+
+
+def cyclic_cases(meta):
+    """The reference's alternate walker (backup/sampler_backup.py), unmodified, on its own Graph (whose
+    sampling_index_dict it advances), with numpy's permutations replaced by pre-drawn ones: a first pass
+    draws and records them, a second pass on a fresh graph replays the record and must give the same walks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_sampler_backup', os.path.join(REF, 'backup', 'sampler_backup.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(77001)
+    arrays = {}
+    meta['cyclic'] = []
+    graphs = {'g_small': make_graph(np.random.default_rng(20240611), 40, 12, 150, 6, 5)}
+    cases = [('g_small', [3, 2], [[0, 51, 7], [7, 7, 39]]),            # two calls in a row: the cursors carry over
+             ('g_small', [8, 4], [[39, 51, 3, 3]]),                     # user 39 / item 51: one neighbor each, k > length
+             ('g_small', [4, 3, 2], [[5, 45], [45, 5, 40]]),
+             ('g_small', [70], [[40, 2]])]                               # more samples than lanes in a wavefront
+    for ci, (gname, ns, calls) in enumerate(cases):
+        feats, nodes, edges = graphs[gname]
+        # pass 1 draws the permutations (and records them); pass 2 replays them on a fresh graph
+        drawn = []
+
+        class Drawer:
+            def permutation(self, x):
+                p = rng.permutation(len(x))
+                drawn.append(p)
+                return np.asarray(x)[p]
+        g = ref_graph.Graph(feats, nodes, edges)
+        mod.np_rn = Drawer()
+        w = mod.BreadthFirstWalker(g, ns)
+        first = [w.run_breadth_first_walk(list(c)) for c in calls]
+        g2 = ref_graph.Graph(feats, nodes, edges)
+        mod.np_rn = TapePermutation(drawn)
+        w2 = mod.BreadthFirstWalker(g2, ns)
+        again = [w2.run_breadth_first_walk(list(c)) for c in calls]
+        assert again == first and mod.np_rn.pos == len(drawn)
+        key = 'cyclic%d' % ci
+        meta['cyclic'].append({'key': key, 'graph': gname, 'num_samples': ns, 'calls': [list(map(int, c)) for c in calls],
+                               'n_perms': len(drawn)})
+        arrays[key + '_perm_lengths'] = np.asarray([len(p) for p in drawn], dtype=np.int64)
+        arrays[key + '_perms'] = (np.concatenate(drawn) if drawn else np.zeros(0)).astype(np.int32)
+        for k, walks in enumerate(first):
+            for h, hop in enumerate(flatten_walks(walks, ns)):
+                arrays['%s_call%d_hop%d' % (key, k, h + 1)] = hop.astype(np.int32)
+        n_all = feats['user'].shape[0] + feats['item'].shape[0]
+        arrays[key + '_cursor'] = np.asarray([g.sampling_index_dict[v] for v in range(n_all)], dtype=np.int64)
+        if ci == 0:
+            meta['cyclic0_nested'] = first
+    return arrays
+
+
 def main():
     meta = {}
     arrays = {}
@@ -333,6 +398,7 @@ def main():
     arrays.update(replay_cases(meta))
     error_cases(meta)
     sequence_cases(meta)
+    arrays.update(cyclic_cases(meta))
     np.savez_compressed(os.path.join(OUT, 'reference_vectors.npz'), **arrays)
     with open(os.path.join(OUT, 'reference_vectors.json'), 'w') as f:
         json.dump(meta, f, indent=1, sort_keys=True)

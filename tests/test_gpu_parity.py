@@ -964,3 +964,81 @@ def test_engines_without_bias_and_without_normalisation(cuda, ns, sizes, f):
     for out in outs:
         for k in range(2):
             close(out[k], want[k], scale=float(want[k].abs().max()))
+
+
+# ----------------------------- the reference's cyclic walker (backup/sampler_backup.py) ----
+
+def _cyclic_perms(arrays, key):
+    lengths, flat, out, pos = arrays[key + '_perm_lengths'], arrays[key + '_perms'], [], 0
+    for n in lengths:
+        out.append(flat[pos:pos + int(n)])
+        pos += int(n)
+    return out
+
+
+@pytest.mark.parametrize('case', range(4))
+def test_cyclic_walker_replay_is_bit_exact_with_the_reference(golden, cuda, case):
+    """gs_sample_cyclic fed the permutations the reference's backup/sampler_backup.py was given: the same
+    walks call after call (the cursors carry over), the same cursors at the end, the same nested lists."""
+    from graphsage_amd import sampler_backup
+    arrays, meta = golden
+    info = meta['cyclic'][case]
+    key, ns = info['key'], info['num_samples']
+    g = ga.Graph(*golden_graph_parts(arrays, info['graph']))
+    w = sampler_backup.BreadthFirstWalker(g, ns)
+    w.set_replay(_cyclic_perms(arrays, key))
+    nested = []
+    for k, roots in enumerate(info['calls']):
+        walks = w.run_breadth_first_walk(roots)
+        nested.append(walks)
+        for h, hop in enumerate(walker.walks_to_hops(walks, ns)):
+            np.testing.assert_array_equal(hop, arrays['%s_call%d_hop%d' % (key, k, h + 1)])
+    np.testing.assert_array_equal(g.sampling_cursor().cpu().numpy(), arrays[key + '_cursor'])
+    assert int(w._state[0]) == info['n_perms'] and int(w._state[1]) == arrays[key + '_perms'].shape[0]
+    if case == 0:
+        assert nested == meta['cyclic0_nested']
+        assert g.sampling_index_dict == {v: int(c) for v, c in enumerate(arrays[key + '_cursor'])}
+
+
+@pytest.mark.parametrize('ns', [[3, 2], [5, 4, 3], [70]])
+def test_cyclic_walker_with_its_own_permutations_equals_the_oracle(golden, cuda, ns):
+    """Without a tape the permutations come from the Philox-keyed Feistel network; the oracle's statement of
+    the walk with the same generator gives the same ids and cursors, over two calls."""
+    from graphsage_amd import sampler_backup
+    from oracle import cyclic
+    from oracle.graph import OracleGraph
+    arrays, _ = golden
+    parts = golden_graph_parts(arrays, 'g_small')
+    g, og = ga.Graph(*parts), OracleGraph(*parts)
+    n_all = g.num_nodes
+    w = sampler_backup.BreadthFirstWalker(g, ns, seed=0xFEEDC0FFEE)
+    cursor = {v: 0 for v in range(n_all)}
+    perm = cyclic.FeistelPerm(0xFEEDC0FFEE)
+    for roots in ([39, 51, 0, 0, 45], [45, 2, 39]):
+        got = w.run_breadth_first_walk(roots)
+        want = cyclic.walk_cyclic(og, ns, roots, cursor, perm)
+        assert got == want
+    np.testing.assert_array_equal(g.sampling_cursor().cpu().numpy(), [cursor[v] for v in range(n_all)])
+    assert int(w._state[0]) == perm.t
+
+
+def test_cyclic_walker_errors(golden, cuda):
+    from graphsage_amd import sampler_backup
+    arrays, _ = golden
+    g = ga.Graph(*golden_graph_parts(arrays, 'g_small'))
+    with pytest.raises(TypeError):
+        sampler_backup.BreadthFirstWalker(g, (3, 2))
+    w = sampler_backup.BreadthFirstWalker(g, [8, 4])
+    with pytest.raises(KeyError):
+        w.run_breadth_first_walk([10 ** 6])
+    assert w.run_breadth_first_walk([]) == []
+    w.set_replay([])                                              # user 39 has one neighbor: the first visit wraps at once
+    with pytest.raises(ValueError):
+        w.run_breadth_first_walk([39])
+    # a node without neighbors: the reference raises ValueError (sampler_backup.py:100)
+    edges = np.array([[0, 1, 3, 3], [3, 3, 0, 1]])
+    g2 = ga.Graph({'user': np.zeros((3, 2), np.float32), 'item': np.zeros((2, 2), np.float32)},
+                  {'user': [0, 1, 2], 'item': [3, 4]}, edges)
+    g2.indptr                                                     # (user 2 and item 4 have no outgoing edge)
+    with pytest.raises(ValueError):
+        sampler_backup.BreadthFirstWalker(g2, [2, 2]).sample_device(torch.tensor([2], dtype=torch.int32, device=cuda))

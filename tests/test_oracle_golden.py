@@ -195,3 +195,50 @@ def test_keyed_and_vectorised_philox_walks_agree(golden):
     b = walker.walk_vectorised(indptr, indices, roots, [4, 3, 2], rng_seed=1234, first_walk=77)
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+
+
+# ------------------------------------------- the cyclic walker (backup/sampler_backup.py) ----
+
+def _split_perms(arrays, key):
+    lengths = arrays[key + '_perm_lengths']
+    flat = arrays[key + '_perms']
+    out, pos = [], 0
+    for n in lengths:
+        out.append(flat[pos:pos + int(n)])
+        pos += int(n)
+    return out
+
+
+@pytest.mark.parametrize('case', range(4))
+def test_cyclic_walk_restatement_equals_the_reference(golden, case):
+    """oracle.cyclic.walk_cyclic on the permutations the reference's own walker was given: same walks,
+    call after call, and the same cursors at the end."""
+    from oracle import cyclic
+    arrays, meta = golden
+    info = meta['cyclic'][case]
+    key, ns = info['key'], info['num_samples']
+    g = OracleGraph(*golden_graph_parts(arrays, info['graph']))
+    n_all = sum(len(v) for v in g.nodes.values())
+    cursor = {v: 0 for v in range(n_all)}
+    perm = cyclic.TapePerm(_split_perms(arrays, key))
+    nested = []
+    for k, roots in enumerate(info['calls']):
+        walks = cyclic.walk_cyclic(g, ns, roots, cursor, perm)
+        nested.append(walks)
+        for h, hop in enumerate(walker.walks_to_hops(walks, ns)):
+            np.testing.assert_array_equal(hop, arrays['%s_call%d_hop%d' % (key, k, h + 1)])
+    assert perm.pos == info['n_perms']
+    np.testing.assert_array_equal(np.asarray([cursor[v] for v in range(n_all)]), arrays[key + '_cursor'])
+    if case == 0:
+        assert nested == meta['cyclic0_nested']
+
+
+def test_feistel_permutation_is_a_permutation():
+    from oracle import cyclic
+    for n in (1, 2, 3, 5, 16, 17, 100, 257):
+        for t in (0, 1, 2 ** 33 + 5):
+            img = [cyclic.feistel_index(t, n, i, 0x1234ABCD5678) for i in range(n)]
+            assert sorted(img) == list(range(n))
+    a = [cyclic.feistel_index(0, 100, i, 1) for i in range(100)]
+    b = [cyclic.feistel_index(1, 100, i, 1) for i in range(100)]
+    assert a != b and a != list(range(100))
