@@ -167,7 +167,7 @@ void sage2_tail_bwd_kernel(const TailArgs a) {
 
 inline int64_t tail_blocks(int64_t n_pairs) {
     int64_t blocks = (2 * n_pairs + kWaves - 1) / kWaves;
-    return blocks > 512 ? 512 : blocks;
+    return blocks > 256 ? 256 : blocks;
 }
 
 int launch_tail(const TailArgs &a, bool head, hipStream_t s) {

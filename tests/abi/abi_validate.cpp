@@ -243,9 +243,9 @@ int main() {
     REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, odd, f, nullptr));
     REFUSED(GS_ELIMIT, gs_sage2_backward_tail(f, f, f, f, (int64_t)1 << 39, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr));
     EXPECT(gs_sage2_tail_head_workspace(-1, 32) == 0);
-    EXPECT(gs_sage2_tail_head_rows(1) == 1 && gs_sage2_tail_head_rows(4096) == 512 && gs_sage2_tail_head_rows((int64_t)1 << 40) == 512);
+    EXPECT(gs_sage2_tail_head_rows(1) == 1 && gs_sage2_tail_head_rows(4096) == 256 && gs_sage2_tail_head_rows((int64_t)1 << 40) == 256);
     const size_t th = gs_sage2_tail_head_workspace(4096, 32);
-    EXPECT(th == (size_t)512 * 66 * 4);
+    EXPECT(th == (size_t)256 * 66 * 4);
     REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, f, f, f, 0, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr));
     REFUSED(GS_ELIMIT, gs_sage2_backward_tail_head(f, f, f, f, f, f, f, 8, 25, 32, 128, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr));
     REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, nullptr, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr));
