@@ -11,28 +11,36 @@
 //                    half the n_child rows of every head are summed as they arrive,
 //                    16 bytes per lane, eight lanes per row, and scaled by 1/n_child;
 //                    the own-row half is the same code with one "child", the head
-//                    itself.  The slice goes into one of two LDS stages in MFMA
+//                    itself.  The slice goes into one of kStages LDS stages in MFMA
 //                    fragment order.  A thread keeps the loads of two slices in
-//                    flight: while slice s is multiplied, slice s+1 moves from
-//                    registers to LDS and the loads of slice s+3 are issued behind
-//                    those of s+2.  These loads are issued and waited for by hand
+//                    flight.  These loads are issued and waited for by hand
 //                    (see load16_async): the compiler's own bookkeeping turns every
-//                    wait into a wait for all loads in flight.
+//                    wait into a wait for all loads in flight.  Every wave stages the
+//                    row ids of its own 16 heads of a tile in a private LDS patch, one
+//                    tile ahead, so that producers never wait for one another.
 //   consumer waves   four waves, each a 64x64 quarter of the tile: one
 //                    ds_read_b128 per 16x16 fragment feeds four
-//                    v_mfma_f32_16x16x4_f32.  They also fetch the 32 x 128 weight
-//                    slice of the next k slice before the multiply (16-byte pieces of
-//                    the row-major weight, which is the order the lanes read them in:
-//                    MFMA j of a lane covers column 4r + j) and put it into the other
-//                    LDS stage after it.  Bias, activation and 16-byte row stores go
-//                    through a wave-private LDS patch (storing straight from the
-//                    accumulators, which hold four consecutive columns per row, was
+//                    v_mfma_f32_16x16x4_f32.  The weight fragments come straight from
+//                    global memory (the weights stay in L2) in the order the lanes use
+//                    them -- MFMA j of a lane covers column 4r + j, so a lane reads 16
+//                    bytes of a weight row -- and each register is reloaded for the next
+//                    slice as soon as its k step has been issued, which puts seven k steps
+//                    between a load and its use.  Bias, activation and 16-byte row
+//                    stores go through a wave-private LDS patch (storing straight from
+//                    the accumulators, which hold four consecutive columns per row, was
 //                    measured 8 % slower: the next tile's MFMAs then wait for the
 //                    stores to have read their registers).
 //
-// All waves meet at one barrier per k slice.  Row ids of a tile (node id - table
-// offset, or "counts as zeros") are staged in LDS one tile ahead.  Neither the
-// gathered rows nor the means go through memory; when the caller asks for copies
+// The two sides meet only through the stages: a producer wave adds one to full[stage] after its
+// part of a slice is written, a consumer wave adds one to empty[stage] after its reads of the stage
+// have been issued (a wave's LDS operations execute in order, so the counter is behind them), and
+// each side waits for the count that says the other is done with the stage -- eight producer parts
+// before a slice is multiplied, four consumer reads before it is overwritten.  There is no block
+// barrier in the loop: producers run ahead by up to kStages slices in LDS plus two in registers,
+// which is what absorbs the spread of the row loads' latency.  Every wait is a bounded spin (a
+// block whose count never arrives writes NaN to its first output element instead of hanging).
+//
+// Neither the gathered rows nor the means go through memory; when the caller asks for copies
 // (save_self / save_mean, for a backward pass) the producers also write each
 // finished piece there.
 #include "fused_args.h"
@@ -40,6 +48,12 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+// Pointers built from integers are generic to the compiler, and a generic ("flat") access may be an
+// LDS access: while one is pending every wait for a load becomes a wait for all of them.  These
+// say "global memory" outright.
+using gf32x4 = __attribute__((address_space(1))) f32x4;
+__device__ __forceinline__ const gf32x4 *global_cptr(const void *p) { return (const gf32x4 *)(unsigned long long)p; }
+__device__ __forceinline__ gf32x4 *global_ptr(unsigned long long p) { return (gf32x4 *)p; }
 using gs::FusedArgs;
 using gs::Seg;
 using gs::kMaxSegs;
@@ -48,7 +62,11 @@ constexpr int WM = 128, WN = 128, WK = 32;
 constexpr int W_TILE = WM * WK;                 // floats of one operand slice (A or B): 16 KB
 constexpr int EP_LD = 68;                       // row stride of the epilogue patch (lane quarters 16 banks apart)
 constexpr int kConsumerThreads = 256;           // four waves, 2 x 2 quarters of the tile
+constexpr int kConsumerWaves = 4, kProducerWaves = 8;
 constexpr int kMaxChild = 32;
+constexpr int kStages = 4;                      // LDS stages of the operand slice
+constexpr int kWaveRows = WM / kProducerWaves;  // heads of a tile whose rows one producer wave fetches: 16
+constexpr int kSpinLimit = 1 << 22;             // polls before a wait gives up (each tens of cycles or more)
 
 // Hand-off through a wave-private LDS patch: a wave's LDS instructions execute in order, so only the
 // compiler has to keep them in order (a workgroup-scope fence here would also wait for the wave's
@@ -62,6 +80,40 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Block barrier for the LDS hand-offs of this kernel: LDS writes done, then s_barrier.  (__syncthreads
 // also fences global memory, which would wait for every gather load in flight at each barrier.)
 __device__ __forceinline__ void block_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Keeps a branch a branch (see Producer::accumulate).
+__device__ __forceinline__ void kBranch() { asm volatile(""); }
+
+// Counters in LDS that hand a stage from one side to the other.  flag_add comes after the wave's
+// earlier LDS operations in program order and LDS executes a wave's operations in order, so no wait
+// is needed before it (a workgroup-scope release would also wait for the wave's global loads).
+__device__ __forceinline__ void flag_add(uint32_t *f) {
+#ifdef WIDE_DIAG_NO_FLAGS                                   // timing aid: no hand-over at all (results are garbage)
+    return;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t flag_peek(const uint32_t *f) {
+#ifdef WIDE_DIAG_NO_FLAGS
+    return 0u;
+#endif
+    return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// true once *f has reached `need` (counters only grow; the difference is compared, so wrapping is harmless)
+__device__ __forceinline__ bool flag_wait(const uint32_t *f, uint32_t need, uint32_t seen) {
+#ifdef WIDE_DIAG_NO_FLAGS
+    return true;
+#endif
+    int spins = 0;
+    while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) - need) < 0) {
+        if (++spins > kSpinLimit) return false;
+        __builtin_amdgcn_s_sleep(1);
+        seen = flag_peek(f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return true;
+}
 
 // Position in a block's sequence of k slices: tile -> column tile -> half -> slice.
 struct Cursor {
@@ -118,32 +170,39 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 
 template <int NPT, int CH, bool BIG>
 struct Producer {
-    static constexpr int PP = 1024 / NPT;            // 16-byte pieces of A (and of B) per thread and slice
-    static constexpr int RSTEP = NPT / 8;            // rows between two pieces of a thread
-    static constexpr int IDT = NPT;
-    static constexpr int IDC = WM * kMaxChild / IDT; // child ids a thread stages per tile, at most
+    static_assert(NPT == 64 * kProducerWaves, "eight producer waves: a wave fetches rows 8w .. 8w+7 and 64+8w .. 64+8w+7 of a tile");
+    static constexpr int PP = 1024 / NPT;            // 16-byte pieces of A per thread and slice: 2
+    static constexpr int RSTEP = NPT / 8;            // rows between two pieces of a thread: 64
+    static constexpr int IDR = 8 * kMaxChild / 64;   // loads of a lane for the child ids of one run of eight heads, at most
+    static constexpr int IDC = PP * IDR;             // child ids a lane stages per tile, at most
 
     const FusedArgs &a;
     const Shape &sh;
     float *st;
-    uint32_t *hrow, *crow;
-    int ptid, itid, a_kq, a_r0;
+    uint32_t *hrow, *crow;                           // this wave's patches: [2][16] own-row keys, [2][16 * max_child] child keys
+    int ptid, lane, wv, a_kq, a_r0;
     int a_dst[PP];                                   // where this thread's pieces go in an LDS stage (floats)
 
     // a k slice in flight (two per thread)
     struct Slice {
         f32x4 v[PP][CH], acc[PP];
         uint32_t mask;                               // bit p*CH+u: load (p, u) stands in for a zero row
-        int cnt;                                     // children in the chunk in flight
+        int cnt;                                     // children in the chunk in flight (its loads: PP * cnt)
         bool bad;                                    // some lane of this wave has such a load
+        bool fresh;                                  // no chunk has been summed into acc yet
         float inv;
-        uint32_t save_lo[PP], save_hi[PP];           // address (two halves) where a copy of the finished piece goes, or 0
+        unsigned long long save_base;                // uniform: where copies of the finished pieces go (0: nowhere), and
+        uint32_t save_off[PP];                       // this thread's byte offsets from it (kNoKey: not this piece)
     };
     // ids in flight
     int32_t cv[IDC], hv;
+    bool clean[2];                                   // per id patch: every key of this wave's heads names a table row
 
-    __device__ __forceinline__ Producer(const FusedArgs &a_, const Shape &sh_, float *st_, uint32_t *hrow_, uint32_t *crow_, int ptid_, int itid_)
-        : a(a_), sh(sh_), st(st_), hrow(hrow_), crow(crow_), ptid(ptid_), itid(itid_), a_kq(ptid_ & 7), a_r0(ptid_ >> 3) {
+    __device__ __forceinline__ Producer(const FusedArgs &a_, const Shape &sh_, float *st_, uint32_t *hrow_, uint32_t *crow_, int ptid_)
+        : a(a_), sh(sh_), st(st_), ptid(ptid_), lane(ptid_ & 63), wv(__builtin_amdgcn_readfirstlane(ptid_ >> 6)),
+          a_kq(ptid_ & 7), a_r0(ptid_ >> 3) {
+        hrow = hrow_ + wv * 2 * kWaveRows;
+        crow = crow_ + wv * 2 * kWaveRows * a.max_child;
 #pragma unroll
         for (int p = 0; p < PP; ++p) {
             const int row = p * RSTEP + a_r0;
@@ -156,58 +215,90 @@ struct Producer {
     // 16 bytes at base + offset, issued without the compiler knowing that the result arrives later:
     // the compiler places its own waits by a conservative count of what may be in flight, which, with
     // two slices per thread and branches around, comes out as "wait for everything".  These loads are
-    // waited for by hand (wait_last_chunk), knowing that every begin() ends with exactly PP*CH of them.
+    // waited for by hand (wait_last_chunk), knowing that a begin() leaves exactly PP * cnt of them in
+    // flight.
     __device__ __forceinline__ static f32x4 load16_async(const char *base, uint32_t off) {
         f32x4 r;
+#ifdef WIDE_DIAG_NO_GATHER                                  // timing aid (-DWIDE_DIAG_NO_GATHER): everything but the row loads
+        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(off), "s"(base) : "memory");
+#else
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+#endif
         return r;
     }
     __device__ __forceinline__ static f32x4 load16_async(const char *addr) {
         f32x4 r;
+#ifdef WIDE_DIAG_NO_GATHER
+        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"((uint32_t)(unsigned long long)addr) : "memory");
+#else
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(addr) : "memory");
+#endif
         return r;
     }
 
-    // cnt (<= CH) children of every piece, starting at child c0: always CH loads per piece, none of
-    // them conditional; a zero row is fetched from row 0 and dropped when the chunk is added, slots
-    // past cnt repeat the last child (a cache hit).  `base` is the table shifted to this slice's first
-    // column (uniform), `fb` the bytes of a table row.  ASYNC: see load16_async.
-    template <bool ASYNC>
-    __device__ __forceinline__ void load_chunk(Slice &s, const char *__restrict__ base, uint32_t fb, const uint32_t *rows, int n, int c0, int cnt) {
+    // Children c0 .. c0 + cnt - 1 (cnt <= CH) of every piece.  ONE: the chunk is a single child (the
+    // own rows): PP loads.  Otherwise always CH loads per piece, none of them conditional: slots past
+    // cnt repeat the last child (a cache hit) and are left out of the sum.  `base` is the table shifted
+    // to this slice's first column (uniform), `fb` the bytes of a table row.  With CLEAN (every key of
+    // the tile names a row) nothing is checked; otherwise a zero row is fetched from row 0 and dropped
+    // when the chunk is added.  ASYNC: see load16_async.
+    template <bool ONE, bool ASYNC, bool CLEAN>
+    __device__ __forceinline__ void load_chunk_n(Slice &s, const char *__restrict__ base, uint32_t fb, const uint32_t *mine, int n, int cnt) {
+        constexpr int NU = ONE ? 1 : CH;
         uint32_t mask = 0u;                          // bit p*CH+u: load (p, u) stands in for a zero row
-        uint32_t key[PP][CH];                        // all keys first: the LDS reads overlap instead of alternating with loads
+        uint32_t key[PP][NU];                        // all keys first: the LDS reads overlap instead of alternating with loads
 #pragma unroll
         for (int p = 0; p < PP; ++p)
 #pragma unroll
-            for (int u = 0; u < CH; ++u) key[p][u] = rows[(p * RSTEP + a_r0) * n + c0 + min(u, cnt - 1)];
+            for (int u = 0; u < NU; ++u) key[p][u] = mine[p * 8 * n + min(u, cnt - 1)];
 #pragma unroll
         for (int p = 0; p < PP; ++p)
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const bool none = key[p][u] == kNoKey;
-                mask |= none ? 1u << (p * CH + u) : 0u;
-                const uint32_t k = none ? 0u : key[p][u];
-#ifdef WIDE_DIAG_NO_GATHER                              // timing aid (-DWIDE_DIAG_NO_GATHER): everything but the row loads
-                s.v[p][u] = f32x4{1.f, 1.f, 1.f, (float)k};
-                continue;
-#endif
-                if (ASYNC) {
-                    if (BIG) s.v[p][u] = load16_async(base + (unsigned long long)k * fb + (uint32_t)(a_kq * 16));
-                    else s.v[p][u] = load16_async(base, k + (uint32_t)(a_kq * 16));
-                } else {
-                    if (BIG) s.v[p][u] = *reinterpret_cast<const f32x4 *>(base + (unsigned long long)k * fb + (uint32_t)(a_kq * 16));
-                    else s.v[p][u] = *reinterpret_cast<const f32x4 *>(base + (k + (uint32_t)(a_kq * 16)));
+            for (int u = 0; u < NU; ++u) {
+                uint32_t k = key[p][u];
+                if (!CLEAN) {
+                    const bool none = k == kNoKey;
+                    mask |= none ? 1u << (p * CH + u) : 0u;
+                    k = none ? 0u : k;
                 }
+                if (BIG) s.v[p][u] = load16_async(base + (unsigned long long)k * fb + (uint32_t)(a_kq * 16));
+                else s.v[p][u] = load16_async(base, k + (uint32_t)(a_kq * 16));
             }
+        if (!ASYNC) {                                // a chunk that is summed right away: loads return in order, so
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // "all of mine" is "all": the older ones are done before them
+#pragma unroll
+            for (int p = 0; p < PP; ++p)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(s.v[p][u]));
+        }
+        // (the registers this shape leaves alone count as written too, at no cost: a register written on
+        // one path only stays live across the other, and the allocator then runs out)
+#pragma unroll
+        for (int p = 0; p < PP; ++p)
+#pragma unroll
+            for (int u = NU; u < CH; ++u) asm volatile("" : "=v"(s.v[p][u]));
         s.mask = mask;
-        s.bad = __any(mask != 0u);
+        s.bad = CLEAN ? false : (bool)__any(mask != 0u);
         s.cnt = cnt;
     }
+    template <bool ASYNC>
+    __device__ __forceinline__ void load_chunk(Slice &s, const char *__restrict__ base, uint32_t fb, const uint32_t *rows, int n, int c0, int cnt, bool clean) {
+        const uint32_t *mine = rows + (lane >> 3) * n + c0;
+        if (ASYNC && cnt == 1) {                                   // uniform
+            if (clean) load_chunk_n<true, ASYNC, true>(s, base, fb, mine, n, 1);
+            else load_chunk_n<true, ASYNC, false>(s, base, fb, mine, n, 1);
+        } else {
+            if (clean) load_chunk_n<false, ASYNC, true>(s, base, fb, mine, n, cnt);
+            else load_chunk_n<false, ASYNC, false>(s, base, fb, mine, n, cnt);
+        }
+    }
 
-    // the PP*CH loads this thread issued BEFORE its latest PP*CH have arrived
-    __device__ __forceinline__ void wait_last_chunk(Slice &s) {
+    // the loads of this slice's last chunk have arrived: everything but the chunk of `newer` children
+    // per piece that this thread issued after them (PP loads if that is one child, PP * CH otherwise)
+    __device__ __forceinline__ void wait_last_chunk(Slice &s, int newer) {
         static_assert(PP * CH <= 32, "one mask bit per load; vmcnt is a 6-bit count");
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * CH) : "memory");
+        if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");          // uniform
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * CH) : "memory");
 #pragma unroll
         for (int p = 0; p < PP; ++p)
 #pragma unroll
@@ -222,75 +313,94 @@ struct Producer {
 #pragma unroll
                 for (int u = 0; u < CH; ++u) s.v[p][u] = (s.mask >> (p * CH + u)) & 1u ? z4 : s.v[p][u];
         }
-        if (s.cnt == 1) {                                          // own rows
+        // (kBranch in an arm: these conditions are uniform and the arms cheap, which the compiler answers
+        // by computing both arms and selecting per lane -- more vector instructions than either arm)
+        if (s.fresh) {                                             // uniform: the sum starts with child 0
+            kBranch();
+#pragma unroll
+            for (int p = 0; p < PP; ++p) s.acc[p] = s.v[p][0];
+        } else {
+            kBranch();
 #pragma unroll
             for (int p = 0; p < PP; ++p) s.acc[p] += s.v[p][0];
-            return;
         }
-        if (s.cnt == CH) {                                         // the common case without per-child selects
+        s.fresh = false;
+        if (s.cnt == 1) return;                                    // own rows
+        if (s.cnt == CH) {                                         // the common case without per-child branches
+            kBranch();
 #pragma unroll
-            for (int u = 0; u < CH; ++u)
+            for (int u = 1; u < CH; ++u)
 #pragma unroll
                 for (int p = 0; p < PP; ++p) s.acc[p] += s.v[p][u];
             return;
         }
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
+        for (int u = 1; u < CH; ++u) {
             if (u < s.cnt) {                                       // uniform
+                kBranch();
 #pragma unroll
                 for (int p = 0; p < PP; ++p) s.acc[p] += s.v[p][u];
             }
         }
     }
 
-    // loads of one slice: all chunks of children but the last are summed here, the last stays in flight
-    __device__ __forceinline__ void begin(Slice &s, const Cursor &c) {
+    // loads of one slice: all chunks of children but the last are summed here, the last stays in flight.
+    // `clean`: see load_chunk.
+    __device__ __forceinline__ void begin(Slice &s, const Cursor &c, bool clean) {
         const int n = c.side ? c.n_child : 1;
         const int F = c.side ? sh.Fn : sh.Fs;
         const unsigned long long b64 = reinterpret_cast<unsigned long long>(c.side ? a.feat_neigh : a.feat_self) + (size_t)c.ks * (WK * 4);
         const char *__restrict__ base = reinterpret_cast<const char *>(                      // uniform: in scalar registers
             ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b64 >> 32)) << 32) |
             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b64));   // (the builtin returns a signed int)
-        const uint32_t *rows = c.side ? crow + (c.local & 1) * WM * a.max_child : hrow + (c.local & 1) * WM;
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int p = 0; p < PP; ++p) s.acc[p] = z4;
+        const uint32_t *rows = c.side ? crow + (c.local & 1) * kWaveRows * a.max_child : hrow + (c.local & 1) * kWaveRows;
         const uint32_t fb = (uint32_t)F * 4u;
         const int nch = (n + CH - 1) / CH;
+        s.fresh = true;
 #pragma unroll 1
         for (int ch = 0; ch + 1 < nch; ++ch) {
-            load_chunk<false>(s, base, fb, rows, n, ch * CH, CH);
+            load_chunk<false>(s, base, fb, rows, n, ch * CH, CH, clean);
             accumulate(s);
         }
-        load_chunk<true>(s, base, fb, rows, n, (nch - 1) * CH, n - (nch - 1) * CH);
+        load_chunk<true>(s, base, fb, rows, n, (nch - 1) * CH, n - (nch - 1) * CH, clean);
         s.inv = c.side ? c.inv : 1.0f;
         // copies for a backward pass: the own rows / the neighbor means, written once (first column tile)
         float *sv = c.side ? a.save_mean : a.save_self;
+        if (sv && c.ct == 0) {                                     // uniform
+            s.save_base = reinterpret_cast<unsigned long long>(sv + c.row0 * F + c.ks * WK);
 #pragma unroll
-        for (int p = 0; p < PP; ++p) {
-            const int row = p * RSTEP + a_r0;
-            const unsigned long long addr = (sv && c.ct == 0 && row < c.np)
-                ? reinterpret_cast<unsigned long long>(sv + (c.row0 + row) * F + c.ks * WK + a_kq * 4) : 0ull;
-            s.save_lo[p] = (uint32_t)addr;
-            s.save_hi[p] = (uint32_t)(addr >> 32);
+            for (int p = 0; p < PP; ++p) {
+                const int row = p * RSTEP + a_r0;
+                s.save_off[p] = row < c.np ? ((uint32_t)row * (uint32_t)F + (uint32_t)a_kq * 4u) * 4u : kNoKey;
+            }
+        } else {
+            s.save_base = 0ull;
         }
     }
 
-    // the slice in flight: last chunk added, mean taken, both operand slices written to LDS stage `buf`
-    __device__ __forceinline__ void finish(Slice &s, int buf) {
-        float *As = st + buf * 2 * W_TILE;
-        wait_last_chunk(s);
+    // the slice in flight: last chunk added, mean taken, this thread's pieces written to LDS stage `buf`.
+    // `newer`: children per piece in the chunk that the other slice has in flight (issued after this one's).
+    __device__ __forceinline__ void finish(Slice &s, int buf, int newer) {
+        float *As = st + buf * W_TILE;
+        wait_last_chunk(s, newer);
         accumulate(s);
+        if (s.inv != 1.0f) {                                       // uniform
+            kBranch();
 #pragma unroll
-        for (int p = 0; p < PP; ++p) {
-            s.acc[p] *= s.inv;
-            *reinterpret_cast<f32x4 *>(As + a_dst[p]) = s.acc[p];
-            const unsigned long long addr = ((unsigned long long)s.save_hi[p] << 32) | s.save_lo[p];
-            if (addr) *reinterpret_cast<f32x4 *>(addr) = s.acc[p];
+            for (int p = 0; p < PP; ++p) s.acc[p] *= s.inv;
+        }
+#pragma unroll
+        for (int p = 0; p < PP; ++p) *reinterpret_cast<f32x4 *>(As + a_dst[p]) = s.acc[p];
+        if (s.save_base) {                                         // uniform
+#pragma unroll
+            for (int p = 0; p < PP; ++p)
+                if (s.save_off[p] != kNoKey) *global_ptr(s.save_base + s.save_off[p]) = s.acc[p];
         }
     }
 
-    // ids of a tile: loads first, LDS writes later (the loads of the slice in flight are older and done by then)
+    // Row ids of this wave's 16 heads of a tile (two runs of eight consecutive heads, 8 n_child
+    // consecutive child ids each): loads first, LDS writes later (the loads of the slice in flight are
+    // older and done by then).  Patch layout: child key of (run, head j, child c) at (run * 8 + j) * n + c.
     __device__ __forceinline__ void ids_issue(int tile) {
         const Seg &sg = a.seg[find_seg(a, tile)];
         const long long p0 = (long long)(tile - (int)sg.tile0) * WM;
@@ -301,12 +411,18 @@ struct Producer {
         const long long last = (long long)np * n - 1;             // np >= 1: a tile holds at least one head
         if (cids) {                                                // unconditional loads (clamped), sorted out at commit
 #pragma unroll
-            for (int i = 0; i < IDC; ++i) cv[i] = cids[p0 * n + min((long long)(i * IDT + itid), last)];
+            for (int run = 0; run < PP; ++run)
+#pragma unroll
+                for (int i = 0; i < IDR; ++i)
+                    cv[run * IDR + i] = cids[p0 * n + min((long long)(run * RSTEP + 8 * wv) * n + i * 64 + lane, last)];
         } else {
 #pragma unroll
-            for (int i = 0; i < IDC; ++i) cv[i] = (int32_t)(sg.child_row0 + p0 * n + i * IDT + itid);
+            for (int run = 0; run < PP; ++run)
+#pragma unroll
+                for (int i = 0; i < IDR; ++i)
+                    cv[run * IDR + i] = (int32_t)(sg.child_row0 + (p0 + run * RSTEP + 8 * wv) * n + i * 64 + lane);
         }
-        const int hp = min(itid, np - 1);
+        const int hp = min((lane >> 3 & 1) * RSTEP + 8 * wv + (lane & 7), np - 1);
         hv = hids ? hids[p0 + hp] : (int32_t)(sg.self_row0 + p0 + hp);
     }
 
@@ -315,24 +431,43 @@ struct Producer {
         const long long p0 = (long long)(tile - (int)sg.tile0) * WM;
         const int np = (int)min((long long)WM, sg.n_heads - p0);
         const int n = sg.n_child;
-        uint32_t *cdst = crow + parity * WM * a.max_child;
+        uint32_t *cdst = crow + parity * kWaveRows * a.max_child;
         const uint32_t fbn = BIG ? 1u : (uint32_t)sh.Fn * 4u, fbs = BIG ? 1u : (uint32_t)sh.Fs * 4u;
-        // (every loaded id is read here whether it is used or not: a load whose result is never read
-        // would stay "in flight" in the compiler's books and cost a wait wherever its register is reused)
+        // Every loaded id is "read" here, on every path: a load whose only reads sit in blocks that may be
+        // skipped stays in flight in the compiler's books, and wherever its register is reused later --
+        // the accumulators of finish() -- the compiler then waits for all loads, the row loads included.
 #pragma unroll
-        for (int i = 0; i < IDC; ++i) {
-            const int idx = i * IDT + itid;
-            const long long rr = (long long)cv[i] - (sg.child_ids ? a.off_neigh : 0);
-            uint32_t key = kNoKey;                                 // also the slots of heads past the end of the segment
-            if (idx < np * n && (unsigned long long)rr < (unsigned long long)a.n_rows_neigh) key = (uint32_t)rr * fbn;
-            if (idx < WM * n) cdst[idx] = key;
+        for (int i = 0; i < IDC; ++i) asm volatile("" : "+v"(cv[i]));
+        asm volatile("" : "+v"(hv));
+        bool none = false;
+#pragma unroll
+        for (int run = 0; run < PP; ++run) {
+            const int l0 = (run * RSTEP + 8 * wv) * n;
+#pragma unroll
+            for (int i = 0; i < IDR; ++i) {
+                const int idx = i * 64 + lane;
+                const long long rr = (long long)cv[run * IDR + i] - (sg.child_ids ? a.off_neigh : 0);
+                uint32_t key = kNoKey;                             // also the slots of heads past the end of the segment
+                if (l0 + idx < np * n && (unsigned long long)rr < (unsigned long long)a.n_rows_neigh) key = (uint32_t)rr * fbn;
+                if (idx < 8 * n) {
+                    cdst[run * 8 * n + idx] = key;
+                    none |= key == kNoKey;
+                }
+            }
         }
         {
+            const int row = (lane >> 3 & 1) * RSTEP + 8 * wv + (lane & 7);
             const long long rr = (long long)hv - (sg.head_ids ? a.off_self : 0);
             uint32_t key = kNoKey;
-            if (itid < np && (unsigned long long)rr < (unsigned long long)a.n_rows_self) key = (uint32_t)rr * fbs;
-            if (itid < WM) hrow[parity * WM + itid] = key;
+            if (row < np && (unsigned long long)rr < (unsigned long long)a.n_rows_self) key = (uint32_t)rr * fbs;
+            if (lane < kWaveRows) {
+                hrow[parity * kWaveRows + lane] = key;
+                none |= key == kNoKey;
+            }
         }
+        const bool ok = !__any(none);
+        if (parity) clean[1] = ok; else clean[0] = ok;
+        wave_lds_fence();                                          // read back by this wave only
     }
 };
 
@@ -341,10 +476,12 @@ template <int NPT, int CH, bool BIG>
 __global__ __launch_bounds__(kConsumerThreads + NPT)
 void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int HH) {
     extern __shared__ __align__(16) float w_smem[];
-    float *st = w_smem;                                            // two stages of [A slice | B slice]
-    float *ep = st + 4 * W_TILE;                                   // four epilogue patches [16][EP_LD]
-    uint32_t *hrow = reinterpret_cast<uint32_t *>(ep + 4 * 16 * EP_LD); // [2][WM] keys of the own rows of a tile
-    uint32_t *crow = hrow + 2 * WM;                                 // [2][WM * max_child] child rows of a tile
+    float *st = w_smem;                                            // kStages operand slices
+    float *ep = st + kStages * W_TILE;                             // four epilogue patches [16][EP_LD]
+    uint32_t *full = reinterpret_cast<uint32_t *>(ep + 4 * 16 * EP_LD);  // [kStages] producer parts written, ever
+    uint32_t *empty = full + kStages;                              // [kStages] consumer reads issued, ever
+    uint32_t *hrow = empty + kStages;                              // [8 waves][2][16] keys of the own rows of a tile
+    uint32_t *crow = hrow + kProducerWaves * 2 * kWaveRows;        // [8 waves][2][16 * max_child] child rows of a tile
 
     const int tid = threadIdx.x;
     Shape sh;
@@ -353,54 +490,75 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     sh.stride = (int)gridDim.x;
     const int n_tiles = (int)a.n_tiles;
     const int my_tiles = (n_tiles - (int)blockIdx.x + sh.stride - 1) / sh.stride;
-    const int T = my_tiles * sh.nct * (sh.ns + sh.nn);              // k slices (= barriers) of this block
+    const int T = my_tiles * sh.nct * (sh.ns + sh.nn);              // k slices of this block
     const int H = 2 * HH;
+    bool stalled = false;                                          // some wait of this wave gave up
+
+    if (tid < 2 * kStages) full[tid] = 0u;
+    block_sync();                                                  // the only block barrier
 
     if (tid >= kConsumerThreads) {
-        Producer<NPT, CH, BIG> pr(a, sh, st, hrow, crow, tid - kConsumerThreads, tid - kConsumerThreads);
+#ifdef WIDE_PRIO_PRODUCER
+        __builtin_amdgcn_s_setprio(WIDE_PRIO_PRODUCER);
+#endif
+        Producer<NPT, CH, BIG> pr(a, sh, st, hrow, crow, tid - kConsumerThreads);
         typename Producer<NPT, CH, BIG>::Slice s0, s1;             // slices of even / odd index
         Cursor cl{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0};      // next slice to load
         enter_tile(cl, a);
-        Cursor cc = cl;                                            // slice the consumers multiply
+        Cursor cc = cl;                                            // slice that goes to LDS next
         int gl = 0;                                                // index of cl; past the last slice it stays there
-        // (the surplus loads and LDS writes at the end are harmless and keep the loop free of branches
-        // around loads, which is what lets a wait for one slice leave the next one in flight)
+        // (the surplus loads at the end are harmless and keep the loop free of branches around loads,
+        // which is what lets a wait for one slice leave the next one in flight)
 #define WD_NEXT() { if (gl + 1 < T) { advance(cl, sh, a); ++gl; } }
+        pr.clean[0] = pr.clean[1] = false;
         pr.ids_issue(cl.tile);
         pr.ids_commit(cl.tile, 0);
-        block_sync();
-        pr.begin(s0, cl); WD_NEXT()
-        pr.begin(s1, cl); WD_NEXT()
-        pr.finish(s0, 0);
-        pr.begin(s0, cl); WD_NEXT()
-        block_sync();
-        // While the consumers multiply slice g: slice g+1 goes from registers to the other LDS stage
-        // (its loads were issued two barriers ago), then the freed registers take the loads of slice g+3.
-#define WD_TICK(S_, buf_)                                                                           \
+#define WD_BEGIN(S_) pr.begin(S_, cl, (cl.local & 1) ? pr.clean[1] : pr.clean[0]); WD_NEXT()
+        WD_BEGIN(s0)
+        WD_BEGIN(s1)
+        int stage = 0;
+        uint32_t use = 0;                                          // times `stage` has been filled before
+        // Slice g: wait until the consumers have read what the stage held, move the slice from registers
+        // to the stage (its loads were issued two slices ago), then the freed registers take the loads of
+        // slice g+2.  At the first slice of a tile the ids of the block's next tile are staged.
+#ifdef WIDE_DIAG_IDLE_PRODUCERS                              // timing aid: the producers only hand stages over
+#define WD_PRODUCE(S_, O_) flag_add(full + stage); WD_NEXT() (void)stage_ids;
+#else
+#define WD_PRODUCE(S_, O_)                                                                          \
+            pr.finish(S_, stage, O_.cnt);                                                           \
+            flag_add(full + stage);                                                                 \
+            WD_BEGIN(S_)                                                                            \
+            if (stage_ids) { pr.ids_issue(next_tile); pr.ids_commit(next_tile, (cc.local + 1) & 1); }
+#endif
+#define WD_TICK(S_, O_)                                                                             \
         {                                                                                           \
             const int next_tile = cc.tile + sh.stride;                                              \
             const bool stage_ids = cc.ct == 0 && cc.side == 0 && cc.ks == 0 && next_tile < n_tiles; \
-            pr.finish(S_, buf_);                                                                    \
-            pr.begin(S_, cl); WD_NEXT()                                                             \
-            if (stage_ids) { pr.ids_issue(next_tile); pr.ids_commit(next_tile, (cc.local + 1) & 1); } \
+            if (use && !flag_wait(empty + stage, use * kConsumerWaves, flag_peek(empty + stage))) stalled = true; \
+            WD_PRODUCE(S_, O_)                                                                      \
             advance(cc, sh, a);                                                                     \
-            block_sync();                                                                           \
+            if (++stage == kStages) { stage = 0; ++use; }                                           \
         }
         for (int g = 0; g < T; g += 2) {
-            WD_TICK(s1, 1)
-            if (g + 1 < T) WD_TICK(s0, 0)
+            WD_TICK(s0, s1)
+            if (g + 1 < T) WD_TICK(s1, s0)
         }
 #undef WD_TICK
+#undef WD_PRODUCE
+#undef WD_BEGIN
 #undef WD_NEXT
+        if (stalled && (tid & 63) == 0) a.out[0] = __builtin_nanf("");
         return;
     }
 
     // ---- consumers ----
+#ifdef WIDE_PRIO_CONSUMER
+    __builtin_amdgcn_s_setprio(WIDE_PRIO_CONSUMER);
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // the wave index as a scalar
     const int wave_m = wave & 1, wave_n = wave >> 1;
     const int r = lane & 15, q = lane >> 4;
     const int a_slot0 = q * 16 + ((r + 2 * q) & 15), a_slot1 = q * 16 + ((r + 2 * (q + 4)) & 15);
-    float *E = ep + wave * 16 * EP_LD;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -410,6 +568,12 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
 
     // bias, activation, store of a finished 128x128 product (this wave's 64x64 quarter), 16 rows at a time
     auto epilogue = [&](const Cursor &d) {
+        // (lane-dependent offsets are derived here from a value the compiler cannot see through: hoisted
+        // out of the slice loop they would occupy two dozen registers that the loop has no room for)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int r = lane_e & 15, q = lane_e >> 4;
+        float *E = ep + wave * 16 * EP_LD;
         const Seg &sg = a.seg[find_seg(a, d.tile)];
         const long long p0 = (long long)(d.tile - (int)sg.tile0) * WM;
         const int np = (int)min((long long)WM, sg.n_heads - p0);
@@ -443,100 +607,95 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         }
     };
 
-    f32x4 aX0, aX1, aX2, aX3, bX0, bX1, bX2, bX3;
-#define WD_READ(S_, base_, half_, slot_)                                                            \
+    // a##S##i: row tile i, element st = k step (k = 16 half + 4q + st); b##S##st: k step st, element j =
+    // column tile (columns 4r + j)
+    f32x4 aX0, aX1, aX2, aX3, aY0, aY1, aY2, aY3;
+#ifdef WIDE_DIAG_NO_A
+    aX0 = aX1 = aX2 = aX3 = aY0 = aY1 = aY2 = aY3 = f32x4{1.f, 1.f, 1.f, 1.f};
+#endif
+    f32x4 bX0, bX1, bX2, bX3, bY0, bY1, bY2, bY3;
+#ifdef WIDE_DIAG_NO_B
+    bX0 = bX1 = bX2 = bX3 = bY0 = bY1 = bY2 = bY3 = f32x4{1.f, 1.f, 1.f, 1.f};
+#endif
+#ifdef WIDE_DIAG_NO_A                                        // timing aid: no fragment reads from LDS
+#define WD_READ_A(S_, base_, half_, slot_) asm volatile("" : "+v"(a##S_##0), "+v"(a##S_##1), "+v"(a##S_##2), "+v"(a##S_##3) : "v"(base_), "v"(slot_));
+#else
+#define WD_READ_A(S_, base_, half_, slot_)                                                          \
     {                                                                                               \
         const float *As_r = (base_) + ((half_) * 8 + wave_m * 4) * 256 + (slot_) * 4;               \
-        const float *Bs_r = (base_) + W_TILE + ((half_) * 8 + wave_n) * 256 + lane * 4;             \
         a##S_##0 = *reinterpret_cast<const f32x4 *>(As_r);                                          \
-        b##S_##0 = *reinterpret_cast<const f32x4 *>(Bs_r);                                          \
         a##S_##1 = *reinterpret_cast<const f32x4 *>(As_r + 256);                                    \
-        b##S_##1 = *reinterpret_cast<const f32x4 *>(Bs_r + 512);                                    \
         a##S_##2 = *reinterpret_cast<const f32x4 *>(As_r + 512);                                    \
-        b##S_##2 = *reinterpret_cast<const f32x4 *>(Bs_r + 1024);                                   \
         a##S_##3 = *reinterpret_cast<const f32x4 *>(As_r + 768);                                    \
-        b##S_##3 = *reinterpret_cast<const f32x4 *>(Bs_r + 1536);                                   \
     }
-    // a##S##i: row tile i, element st = k step; b##S##st: k step st, element j = column tile (columns 4r + j)
+#endif
 #define WD_MFMA_ROW(i_, av_, bv_, st_)                                                              \
     acc[i_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[0], acc[i_][0], 0, 0, 0);       \
     acc[i_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[1], acc[i_][1], 0, 0, 0);       \
     acc[i_][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[2], acc[i_][2], 0, 0, 0);       \
     acc[i_][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[3], acc[i_][3], 0, 0, 0);
+#ifdef WIDE_DIAG_NO_MFMA                                    // timing aid (-DWIDE_DIAG_NO_MFMA): everything but the matrix instructions
+#define WD_MFMA_STEP(S_, st_) asm volatile("" :: "v"(a##S_##0), "v"(a##S_##1), "v"(a##S_##2), "v"(a##S_##3), "v"(b##S_##st_));
+#else
 #define WD_MFMA_STEP(S_, st_)                                                                       \
     WD_MFMA_ROW(0, a##S_##0, b##S_##st_, st_) WD_MFMA_ROW(1, a##S_##1, b##S_##st_, st_)             \
     WD_MFMA_ROW(2, a##S_##2, b##S_##st_, st_) WD_MFMA_ROW(3, a##S_##3, b##S_##st_, st_)
-#ifdef WIDE_DIAG_NO_MFMA                                    // timing aid (-DWIDE_DIAG_NO_MFMA): everything but the matrix instructions
-#define WD_MFMA(S_) asm volatile("" :: "v"(a##S_##0), "v"(a##S_##1), "v"(a##S_##2), "v"(a##S_##3), "v"(b##S_##0), "v"(b##S_##1), "v"(b##S_##2), "v"(b##S_##3));
-#else
-#define WD_MFMA(S_) WD_MFMA_STEP(S_, 0) WD_MFMA_STEP(S_, 1) WD_MFMA_STEP(S_, 2) WD_MFMA_STEP(S_, 3)
 #endif
+    // Weight fragment of k step st of a half slice: W[ks * 32 + 16 half + 4q + st][column tile + 64 wave_n + 4r .. + 3],
+    // 16 lanes on 256 consecutive bytes of each of four weight rows.
+    const float *Wb;                                                // this lane's piece of k step 0 of the half being loaded
+#define WD_B_BASE(cur_, half_)                                                                      \
+    Wb = ((cur_).side ? a.W_neigh : a.W_self) + (long long)((cur_).ks * WK + (half_) * 16 + 4 * q) * HH + (cur_).ct * WN + wave_n * 64 + 4 * r;
+#ifdef WIDE_DIAG_NO_B                                        // timing aid (-DWIDE_DIAG_NO_B): everything but the weight loads
+#define WD_LOAD_B(S_, st_) asm volatile("" : "+v"(b##S_##st_) : "v"(Wb));
+#else
+#define WD_LOAD_B(S_, st_) b##S_##st_ = *reinterpret_cast<const f32x4 *>(Wb + (st_) * HH);
+#endif
+    // one k step of a half, then the reload of its weight register for the next slice
+#define WD_STEP(S_, st_) { WD_MFMA_STEP(S_, st_) __builtin_amdgcn_sched_barrier(0); WD_LOAD_B(S_, st_) __builtin_amdgcn_sched_barrier(0); }
 
-    // weight slices, for the slice after the one being multiplied: a thread fetches four 16-byte pieces
-    // W[k][4c .. 4c+3] of the row-major weight (coalesced: 32 threads cover a 128-column row) and writes
-    // them to the other LDS stage when the multiply is done.  MFMA j of a 64-column group covers the
-    // columns n = 4r + j, so lane (r, q) needs exactly such a piece -- k = 16 half + 4q + st, c = 16 g + r --
-    // for its four MFMAs of k step st: the pieces go to LDS as they are, in the order the lanes read them.
-    // (piece j of this thread: k row (j*256 + tid) >> 5, column piece (j*256 + tid) & 31; the offsets are
-    // recomputed where used rather than kept in registers)
-#define WD_B_ROW(j_) (8 * (j_) + (tid >> 5))
-#define WD_B_C4 (tid & 31)
-#define WD_B_DST(j_) (W_TILE + ((((WD_B_ROW(j_) >> 4) * 4 + (WD_B_ROW(j_) & 3)) * 2 + (WD_B_C4 >> 4)) * 64 + ((WD_B_ROW(j_) >> 2) & 3) * 16 + (WD_B_C4 & 15)) * 4)
-#define WD_B_OFF(j_) ((uint32_t)(WD_B_ROW(j_) * HH + WD_B_C4 * 4))
-    float4 bw0, bw1, bw2, bw3;
-#define WD_LOAD_B(cur_)                                                                             \
-    {                                                                                               \
-        const float *__restrict__ W0 = ((cur_).side ? a.W_neigh : a.W_self) + (long long)((cur_).ks * WK) * HH + (cur_).ct * WN; \
-        bw0 = *reinterpret_cast<const float4 *>(W0 + WD_B_OFF(0));                                  \
-        bw1 = *reinterpret_cast<const float4 *>(W0 + WD_B_OFF(1));                                  \
-        bw2 = *reinterpret_cast<const float4 *>(W0 + WD_B_OFF(2));                                  \
-        bw3 = *reinterpret_cast<const float4 *>(W0 + WD_B_OFF(3));                                  \
-    }
-#define WD_STORE_B(stage_)                                                                          \
-    {                                                                                               \
-        float *Bw = st + (stage_) * 2 * W_TILE;                                                     \
-        *reinterpret_cast<float4 *>(Bw + WD_B_DST(0)) = bw0;                                           \
-        *reinterpret_cast<float4 *>(Bw + WD_B_DST(1)) = bw1;                                           \
-        *reinterpret_cast<float4 *>(Bw + WD_B_DST(2)) = bw2;                                           \
-        *reinterpret_cast<float4 *>(Bw + WD_B_DST(3)) = bw3;                                           \
-    }
-
-    Cursor c{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0}, done = c;
-    bool pending = false;
-    block_sync();
-    WD_LOAD_B(c);
-    WD_STORE_B(0);
-    Cursor cn = c;                                                  // the slice after c
-    advance(cn, sh, a);
-    block_sync();
+    Cursor c{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0};
+    Cursor cn = c;                                                  // the slice after c (the last one stays put)
+    WD_B_BASE(c, 0) WD_LOAD_B(X, 0) WD_LOAD_B(X, 1) WD_LOAD_B(X, 2) WD_LOAD_B(X, 3)
+    WD_B_BASE(c, 1) WD_LOAD_B(Y, 0) WD_LOAD_B(Y, 1) WD_LOAD_B(Y, 2) WD_LOAD_B(Y, 3)
+    if (T > 1) advance(cn, sh, a);
+    if (!flag_wait(full, kProducerWaves, flag_peek(full))) stalled = true;
+    WD_READ_A(X, st, 0, a_slot0);
+    int stage = 0;
+    uint32_t use = 1;                                               // times the stage of slice g has been filled, this one included
     for (int g = 0; g < T; ++g) {
-        if (pending) epilogue(done);
-        const float *S = st + (int)(g & 1) * 2 * W_TILE;
-        if (g + 1 < T) WD_LOAD_B(cn);
+        const float *S = st + stage * W_TILE;
+        int nstage = stage + 1;
+        uint32_t nuse = use;
+        if (nstage == kStages) { nstage = 0; ++nuse; }
+        WD_READ_A(Y, S, 1, a_slot1);
+        flag_add(empty + stage);                                   // all reads of the stage are issued
+        const uint32_t seen = flag_peek(full + nstage);            // (answered while the first half is multiplied)
         __builtin_amdgcn_sched_barrier(0);
-        WD_READ(X, S, 0, a_slot0);
-        WD_MFMA(X);
-        WD_READ(X, S, 1, a_slot1);
-        WD_MFMA(X);
+        WD_B_BASE(cn, 0)
+        WD_STEP(X, 0) WD_STEP(X, 1) WD_STEP(X, 2) WD_STEP(X, 3)
+        if (g + 1 < T) {
+            if (!flag_wait(full + nstage, nuse * kProducerWaves, seen)) stalled = true;
+            WD_READ_A(X, st + nstage * W_TILE, 0, a_slot0);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (g + 1 < T) WD_STORE_B((int)((g + 1) & 1));
-        advance(cn, sh, a);
-        pending = c.ks + 1 == (c.side ? sh.nn : sh.ns);
-        done = c;
+        WD_B_BASE(cn, 1)
+        WD_STEP(Y, 0) WD_STEP(Y, 1) WD_STEP(Y, 2) WD_STEP(Y, 3)
+#ifndef WIDE_DIAG_NO_EPILOGUE
+        if (c.ks + 1 == (c.side ? sh.nn : sh.ns)) epilogue(c);
+#endif
         advance(c, sh, a);
-        block_sync();
+        if (g + 2 < T) advance(cn, sh, a);
+        stage = nstage;
+        use = nuse;
     }
-    if (pending) epilogue(done);
-#undef WD_READ
-#undef WD_LOAD_B
-#undef WD_B_ROW
-#undef WD_B_C4
-#undef WD_B_DST
-#undef WD_B_OFF
-#undef WD_STORE_B
+    if (stalled && lane == 0) a.out[0] = __builtin_nanf("");
+#undef WD_READ_A
 #undef WD_MFMA_ROW
 #undef WD_MFMA_STEP
-#undef WD_MFMA
+#undef WD_B_BASE
+#undef WD_LOAD_B
+#undef WD_STEP
 }
 
 // rows of x scaled to unit l2 norm, in place (one wave per row)
@@ -557,7 +716,8 @@ void l2norm_inplace_kernel(float *x, int64_t M, int H) {
 constexpr int kProducerThreads = 512, kChunk = 5;
 
 inline size_t wide_lds_bytes(int max_child) {
-    return (size_t)(4 * W_TILE + 4 * 16 * EP_LD) * sizeof(float) + (size_t)(2 * WM + 2 * WM * max_child) * sizeof(int32_t);
+    return (size_t)(kStages * W_TILE + 4 * 16 * EP_LD) * sizeof(float) +
+           (size_t)(2 * kStages + 2 * WM + 2 * WM * max_child) * sizeof(int32_t);
 }
 
 }  // namespace

@@ -1,6 +1,9 @@
 """Times one wide fused layer (gs_sage_fused_fwd on 256-wide inputs) on synthetic ids.
 python tools/time_wide.py [heads] [n_child] [table_rows]"""
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
