@@ -30,7 +30,8 @@ _TYPES = ('user', 'item')
 
 
 class SageForwardEngine:
-    def __init__(self, graph, model, batch_size, use_fused=True, walk_kernel=True, keep_ids=False, draw_in_layer=False):
+    def __init__(self, graph, model, batch_size, use_fused=True, walk_kernel=True, keep_ids=False, draw_in_layer=False,
+                 wide_min_rows=128 * 256):
         """draw_in_layer: the layer-0 kernel draws the deepest hop's ids itself instead of reading what
         the sampler kernel wrote (``gs_sage_fused_sampled_fwd``); keep_ids then also leaves those ids
         in ``hops[-1]``.  Off by default: a draw costs one 64-byte sector of the neighbor array wherever
@@ -96,6 +97,12 @@ class SageForwardEngine:
         # and run on the general kernels.
         self.wide_first_layer_only = (use_fused and self.n_hops > 1 and
                                       all(model.dims[1][t] // 2 >= 128 for t in _TYPES))
+        # (forward only: a later layer with at least ``wide_min_rows`` rows, a 128-row tile per compute
+        # unit -- layer 1 of a three-hop model -- takes the wide kernel as well)
+        self.wide_layers = [False] * self.n_hops
+        if self.wide_first_layer_only and all(self.fused_layers):
+            self.wide_layers = [layer == 0 or min(x.shape[0] for x in self.h[layer].values()) >= int(wide_min_rows)
+                                for layer in range(self.n_hops)]
         # two hops: the whole forward pass as one kernel, one wavefront per walk
         self.walk_kernel = bool(use_fused and walk_kernel and self.n_hops == 2 and kernels.sage2_supported(
             f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'], *self.fanouts))
@@ -203,29 +210,36 @@ class SageForwardEngine:
         main.wait_stream(self._side)
         return self._aggregate_tail()
 
-    def _aggregate_tail(self):
-        """Layers 1..L-1 and the normalisation with the general kernels, on layer 0's output."""
+    def _general_layer(self, layer):
+        """Layer ``layer`` >= 1 with the general kernels (neighbor means to memory, then the tiled projection)."""
         m = self.model
         other = self.other
-        for layer in range(1, self.n_hops):
-            for t in _TYPES:
-                for (s, h, side, r0, n) in self.segments[t]:
-                    if h > self.n_hops - 1 - layer:
-                        continue
-                    _, c0, cn = self.where[s + 2]
-                    self._reduce(self.h[layer - 1][other[t]][c0:c0 + cn], None, n, self.fanouts[h],
-                                 out=self.x_mean[layer][t][r0:r0 + n])
-            for t in _TYPES:
-                agg = m._aggs[layer][t]
-                rows = self.h[layer][t].shape[0]
-                kernels.sage_project(self.h[layer - 1][t][:rows], self.x_mean[layer][t][:rows], agg.w_self, agg.w_neigh,
-                                     agg.bias, agg.activation, out=self.h[layer][t])
         for t in _TYPES:
-            if m.normalize == "l2":
+            for (s, h, side, r0, n) in self.segments[t]:
+                if h > self.n_hops - 1 - layer:
+                    continue
+                _, c0, cn = self.where[s + 2]
+                self._reduce(self.h[layer - 1][other[t]][c0:c0 + cn], None, n, self.fanouts[h],
+                             out=self.x_mean[layer][t][r0:r0 + n])
+        for t in _TYPES:
+            agg = m._aggs[layer][t]
+            rows = self.h[layer][t].shape[0]
+            kernels.sage_project(self.h[layer - 1][t][:rows], self.x_mean[layer][t][:rows], agg.w_self, agg.w_neigh,
+                                 agg.bias, agg.activation, out=self.h[layer][t])
+
+    def _normalize_general(self):
+        for t in _TYPES:
+            if self.model.normalize == "l2":
                 kernels.l2_normalize(self.h[-1][t], out=self.emb[t])
             else:
                 self.emb[t].copy_(self.h[-1][t])
         return self.emb['user'], self.emb['item']
+
+    def _aggregate_tail(self):
+        """Layers 1..L-1 and the normalisation with the general kernels, on layer 0's output."""
+        for layer in range(1, self.n_hops):
+            self._general_layer(layer)
+        return self._normalize_general()
 
     # -- fused layers ----------------------------------------------------------------
     def _fused_ok(self, layer):
@@ -306,8 +320,14 @@ class SageForwardEngine:
         if not all(self.fused_layers):
             return self.aggregate(seeds)
         if self.wide_first_layer_only:
-            self._run_fused_layer(0, seeds)
-            return self._aggregate_tail()
+            for layer in range(self.n_hops):
+                if self.wide_layers[layer]:
+                    self._run_fused_layer(layer, seeds)
+                else:
+                    self._general_layer(layer)
+            if self.wide_layers[-1]:
+                return self.emb['user'], self.emb['item']
+            return self._normalize_general()
         for layer in range(self.n_hops):
             self._run_fused_layer(layer, seeds)
         return self.emb['user'], self.emb['item']

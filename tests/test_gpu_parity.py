@@ -615,6 +615,37 @@ def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_
         start += nh
 
 
+def test_engine_wide_kernel_on_every_layer_matches_general_kernels(cuda):
+    """A wide three-hop model with the row threshold lowered so that every layer -- dense activation
+    rows from layer 1 on -- goes through the wide kernel: same embeddings as the general kernels."""
+    from graphsage_amd.engine import SageForwardEngine
+    rng = np.random.default_rng(8)
+    nu, ni, b = 300, 80, 40
+    u = np.concatenate([rng.integers(0, nu, 2500), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 2500), np.arange(nu) % ni]) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, 64)).astype(np.float32),
+             'item': rng.standard_normal((ni, 128)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    ns, sizes = [6, 5, 3], [256, 256, 256]
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=2)
+    model = ga.GraphSAGE(sizes, gen, seed=9).build()
+    seeds = torch.tensor(list(e[0, :b]) + list(e[1, :b]), dtype=torch.int32, device=cuda)
+    walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda)
+    eng_w = SageForwardEngine(g, model, b, wide_min_rows=1)
+    eng_d = SageForwardEngine(g, model, b)                     # default threshold: wide layer 0, general tail
+    eng_u = SageForwardEngine(g, model, b, use_fused=False)
+    assert eng_w.wide_layers == [True, True, True] and eng_d.wide_layers == [True, False, False]
+    out_w = [x.clone() for x in eng_w.forward(seeds, walk_ids, rng_seed=5)]
+    out_d = [x.clone() for x in eng_d.forward(seeds, walk_ids, rng_seed=5)]
+    out_u = [x.clone() for x in eng_u.forward(seeds, walk_ids, rng_seed=5)]
+    for a, c, d in zip(out_w, out_u, out_d):
+        assert bool(torch.isfinite(a).all())
+        close(a, c.double(), scale=float(c.abs().max()))
+        close(d, c.double(), scale=float(c.abs().max()))
+
+
 @pytest.mark.parametrize('ns,sizes,fu,fi', [([8, 4], [32, 32], 64, 64), ([25, 10], [32, 32], 64, 32),
                                             ([4, 3, 2], [32, 64, 32], 32, 64), ([8, 4], [32, 32], 24, 19),
                                             ([5, 3, 2], [256, 256, 256], 64, 128)])     # wide layers: wide kernel
