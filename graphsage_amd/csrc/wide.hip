@@ -88,23 +88,14 @@ __device__ __forceinline__ void kBranch() { asm volatile(""); }
 // earlier LDS operations in program order and LDS executes a wave's operations in order, so no wait
 // is needed before it (a workgroup-scope release would also wait for the wave's global loads).
 __device__ __forceinline__ void flag_add(uint32_t *f) {
-#ifdef WIDE_DIAG_NO_FLAGS                                   // timing aid: no hand-over at all (results are garbage)
-    return;
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ uint32_t flag_peek(const uint32_t *f) {
-#ifdef WIDE_DIAG_NO_FLAGS
-    return 0u;
-#endif
     return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // true once *f has reached `need` (counters only grow; the difference is compared, so wrapping is harmless)
 __device__ __forceinline__ bool flag_wait(const uint32_t *f, uint32_t need, uint32_t seen) {
-#ifdef WIDE_DIAG_NO_FLAGS
-    return true;
-#endif
     int spins = 0;
     while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) - need) < 0) {
         if (++spins > kSpinLimit) return false;
@@ -175,6 +166,7 @@ struct Producer {
     static constexpr int RSTEP = NPT / 8;            // rows between two pieces of a thread: 64
     static constexpr int IDR = 8 * kMaxChild / 64;   // loads of a lane for the child ids of one run of eight heads, at most
     static constexpr int IDC = PP * IDR;             // child ids a lane stages per tile, at most
+    static constexpr int kIdLoads = IDC + 1;         // loads of ids_issue(): the child ids and one head id
 
     const FusedArgs &a;
     const Shape &sh;
@@ -219,20 +211,12 @@ struct Producer {
     // flight.
     __device__ __forceinline__ static f32x4 load16_async(const char *base, uint32_t off) {
         f32x4 r;
-#ifdef WIDE_DIAG_NO_GATHER                                  // timing aid (-DWIDE_DIAG_NO_GATHER): everything but the row loads
-        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(off), "s"(base) : "memory");
-#else
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
-#endif
         return r;
     }
     __device__ __forceinline__ static f32x4 load16_async(const char *addr) {
         f32x4 r;
-#ifdef WIDE_DIAG_NO_GATHER
-        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"((uint32_t)(unsigned long long)addr) : "memory");
-#else
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(addr) : "memory");
-#endif
         return r;
     }
 
@@ -293,12 +277,19 @@ struct Producer {
         }
     }
 
-    // the loads of this slice's last chunk have arrived: everything but the chunk of `newer` children
-    // per piece that this thread issued after them (PP loads if that is one child, PP * CH otherwise)
-    __device__ __forceinline__ void wait_last_chunk(Slice &s, int newer) {
-        static_assert(PP * CH <= 32, "one mask bit per load; vmcnt is a 6-bit count");
-        if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");          // uniform
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * CH) : "memory");
+    // the loads of this slice's last chunk have arrived: everything but what this thread issued after
+    // them -- the other slice's chunk of `newer` children per piece (PP loads if that is one child,
+    // PP * CH otherwise) and, with `ids`, the kIdLoads id loads of ids_issue()
+    __device__ __forceinline__ void wait_last_chunk(Slice &s, int newer, bool ids) {
+        static_assert(PP * CH <= 32, "one mask bit per load");
+        static_assert(PP * CH + kIdLoads < 64, "vmcnt is a 6-bit count");
+        if (!ids) {                                                // uniform
+            if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * CH) : "memory");
+        } else {
+            if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP + kIdLoads) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * CH + kIdLoads) : "memory");
+        }
 #pragma unroll
         for (int p = 0; p < PP; ++p)
 #pragma unroll
@@ -379,10 +370,10 @@ struct Producer {
     }
 
     // the slice in flight: last chunk added, mean taken, this thread's pieces written to LDS stage `buf`.
-    // `newer`: children per piece in the chunk that the other slice has in flight (issued after this one's).
-    __device__ __forceinline__ void finish(Slice &s, int buf, int newer) {
+    // `newer`, `ids`: what this thread issued after this slice's loads (see wait_last_chunk).
+    __device__ __forceinline__ void finish(Slice &s, int buf, int newer, bool ids) {
         float *As = st + buf * W_TILE;
-        wait_last_chunk(s, newer);
+        wait_last_chunk(s, newer, ids);
         accumulate(s);
         if (s.inv != 1.0f) {                                       // uniform
             kBranch();
@@ -399,46 +390,55 @@ struct Producer {
     }
 
     // Row ids of this wave's 16 heads of a tile (two runs of eight consecutive heads, 8 n_child
-    // consecutive child ids each): loads first, LDS writes later (the loads of the slice in flight are
-    // older and done by then).  Patch layout: child key of (run, head j, child c) at (run * 8 + j) * n + c.
+    // consecutive child ids each).  Patch layout: child key of (run, head j, child c) at (run * 8 + j) * n + c.
+    // The loads -- always kIdLoads of them, from a stand-in address where the ids are row numbers that
+    // need no load -- are hidden from the compiler like the row loads, so that they can stay in flight
+    // for a whole slice: ids_commit() waits for them by count.
+    __device__ __forceinline__ static int32_t load4_async(const int32_t *addr) {
+        int32_t r;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(addr) : "memory");
+        return r;
+    }
     __device__ __forceinline__ void ids_issue(int tile) {
         const Seg &sg = a.seg[find_seg(a, tile)];
         const long long p0 = (long long)(tile - (int)sg.tile0) * WM;
         const int np = (int)min((long long)WM, sg.n_heads - p0);
         const int n = sg.n_child;
-        const int32_t *__restrict__ cids = sg.child_ids;
-        const int32_t *__restrict__ hids = sg.head_ids;
-        const long long last = (long long)np * n - 1;             // np >= 1: a tile holds at least one head
-        if (cids) {                                                // unconditional loads (clamped), sorted out at commit
+        const int32_t *standin = reinterpret_cast<const int32_t *>(a.W_self);
+        const int32_t *cids = sg.child_ids ? sg.child_ids + p0 * n : standin;
+        const int32_t *hids = sg.head_ids ? sg.head_ids + p0 : standin;
+        const long long last = sg.child_ids ? (long long)np * n - 1 : 0;   // np >= 1: a tile holds at least one head
 #pragma unroll
-            for (int run = 0; run < PP; ++run)
+        for (int run = 0; run < PP; ++run)
 #pragma unroll
-                for (int i = 0; i < IDR; ++i)
-                    cv[run * IDR + i] = cids[p0 * n + min((long long)(run * RSTEP + 8 * wv) * n + i * 64 + lane, last)];
-        } else {
-#pragma unroll
-            for (int run = 0; run < PP; ++run)
-#pragma unroll
-                for (int i = 0; i < IDR; ++i)
-                    cv[run * IDR + i] = (int32_t)(sg.child_row0 + (p0 + run * RSTEP + 8 * wv) * n + i * 64 + lane);
-        }
-        const int hp = min((lane >> 3 & 1) * RSTEP + 8 * wv + (lane & 7), np - 1);
-        hv = hids ? hids[p0 + hp] : (int32_t)(sg.self_row0 + p0 + hp);
+            for (int i = 0; i < IDR; ++i)                          // unconditional loads (clamped), sorted out at commit
+                cv[run * IDR + i] = load4_async(cids + min((long long)(run * RSTEP + 8 * wv) * n + i * 64 + lane, last));
+        const int hp = sg.head_ids ? min((lane >> 3 & 1) * RSTEP + 8 * wv + (lane & 7), np - 1) : 0;
+        hv = load4_async(hids + hp);
     }
 
-    __device__ __forceinline__ void ids_commit(int tile, int parity) {
+    // `newer`: children per piece of the one chunk of row loads issued after ids_issue() (0: none)
+    __device__ __forceinline__ void ids_commit(int tile, int parity, int newer) {
         const Seg &sg = a.seg[find_seg(a, tile)];
         const long long p0 = (long long)(tile - (int)sg.tile0) * WM;
         const int np = (int)min((long long)WM, sg.n_heads - p0);
         const int n = sg.n_child;
         uint32_t *cdst = crow + parity * kWaveRows * a.max_child;
         const uint32_t fbn = BIG ? 1u : (uint32_t)sh.Fn * 4u, fbs = BIG ? 1u : (uint32_t)sh.Fs * 4u;
-        // Every loaded id is "read" here, on every path: a load whose only reads sit in blocks that may be
-        // skipped stays in flight in the compiler's books, and wherever its register is reused later --
-        // the accumulators of finish() -- the compiler then waits for all loads, the row loads included.
+        if (newer == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // uniform
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * CH) : "memory");
 #pragma unroll
-        for (int i = 0; i < IDC; ++i) asm volatile("" : "+v"(cv[i]));
+        for (int i = 0; i < IDC; ++i) asm volatile("" : "+v"(cv[i]));                       // uses stay behind the wait
         asm volatile("" : "+v"(hv));
+        if (!sg.child_ids) {                                       // rows of an activation buffer: numbered, not loaded
+#pragma unroll
+            for (int run = 0; run < PP; ++run)
+#pragma unroll
+                for (int i = 0; i < IDR; ++i)
+                    cv[run * IDR + i] = (int32_t)(sg.child_row0 + (p0 + run * RSTEP + 8 * wv) * n + i * 64 + lane);
+        }
+        if (!sg.head_ids) hv = (int32_t)(sg.self_row0 + p0 + min((lane >> 3 & 1) * RSTEP + 8 * wv + (lane & 7), np - 1));
         bool none = false;
 #pragma unroll
         for (int run = 0; run < PP; ++run) {
@@ -498,9 +498,6 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     block_sync();                                                  // the only block barrier
 
     if (tid >= kConsumerThreads) {
-#ifdef WIDE_PRIO_PRODUCER
-        __builtin_amdgcn_s_setprio(WIDE_PRIO_PRODUCER);
-#endif
         Producer<NPT, CH, BIG> pr(a, sh, st, hrow, crow, tid - kConsumerThreads);
         typename Producer<NPT, CH, BIG>::Slice s0, s1;             // slices of even / odd index
         Cursor cl{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0};      // next slice to load
@@ -512,7 +509,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
 #define WD_NEXT() { if (gl + 1 < T) { advance(cl, sh, a); ++gl; } }
         pr.clean[0] = pr.clean[1] = false;
         pr.ids_issue(cl.tile);
-        pr.ids_commit(cl.tile, 0);
+        pr.ids_commit(cl.tile, 0, 0);
 #define WD_BEGIN(S_) pr.begin(S_, cl, (cl.local & 1) ? pr.clean[1] : pr.clean[0]); WD_NEXT()
         WD_BEGIN(s0)
         WD_BEGIN(s1)
@@ -520,16 +517,15 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         uint32_t use = 0;                                          // times `stage` has been filled before
         // Slice g: wait until the consumers have read what the stage held, move the slice from registers
         // to the stage (its loads were issued two slices ago), then the freed registers take the loads of
-        // slice g+2.  At the first slice of a tile the ids of the block's next tile are staged.
-#ifdef WIDE_DIAG_IDLE_PRODUCERS                              // timing aid: the producers only hand stages over
-#define WD_PRODUCE(S_, O_) flag_add(full + stage); WD_NEXT() (void)stage_ids;
-#else
+        // slice g+2.  At the first slice of a tile the ids of the block's next tile are requested, ahead
+        // of the row loads of that slice; one slice later they have arrived and go to the id patch.
+        bool ids_wait = false;                                     // id loads in flight, issued in the previous slice
 #define WD_PRODUCE(S_, O_)                                                                          \
-            pr.finish(S_, stage, O_.cnt);                                                           \
+            pr.finish(S_, stage, O_.cnt, ids_wait);                                                 \
             flag_add(full + stage);                                                                 \
-            WD_BEGIN(S_)                                                                            \
-            if (stage_ids) { pr.ids_issue(next_tile); pr.ids_commit(next_tile, (cc.local + 1) & 1); }
-#endif
+            if (ids_wait) { pr.ids_commit(next_tile, (cc.local + 1) & 1, O_.cnt); ids_wait = false; } \
+            if (stage_ids) { pr.ids_issue(next_tile); ids_wait = true; }                            \
+            WD_BEGIN(S_)
 #define WD_TICK(S_, O_)                                                                             \
         {                                                                                           \
             const int next_tile = cc.tile + sh.stride;                                              \
@@ -547,14 +543,12 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
 #undef WD_PRODUCE
 #undef WD_BEGIN
 #undef WD_NEXT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the surplus loads
         if (stalled && (tid & 63) == 0) a.out[0] = __builtin_nanf("");
         return;
     }
 
     // ---- consumers ----
-#ifdef WIDE_PRIO_CONSUMER
-    __builtin_amdgcn_s_setprio(WIDE_PRIO_CONSUMER);
-#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // the wave index as a scalar
     const int wave_m = wave & 1, wave_n = wave >> 1;
     const int r = lane & 15, q = lane >> 4;
@@ -610,16 +604,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     // a##S##i: row tile i, element st = k step (k = 16 half + 4q + st); b##S##st: k step st, element j =
     // column tile (columns 4r + j)
     f32x4 aX0, aX1, aX2, aX3, aY0, aY1, aY2, aY3;
-#ifdef WIDE_DIAG_NO_A
-    aX0 = aX1 = aX2 = aX3 = aY0 = aY1 = aY2 = aY3 = f32x4{1.f, 1.f, 1.f, 1.f};
-#endif
     f32x4 bX0, bX1, bX2, bX3, bY0, bY1, bY2, bY3;
-#ifdef WIDE_DIAG_NO_B
-    bX0 = bX1 = bX2 = bX3 = bY0 = bY1 = bY2 = bY3 = f32x4{1.f, 1.f, 1.f, 1.f};
-#endif
-#ifdef WIDE_DIAG_NO_A                                        // timing aid: no fragment reads from LDS
-#define WD_READ_A(S_, base_, half_, slot_) asm volatile("" : "+v"(a##S_##0), "+v"(a##S_##1), "+v"(a##S_##2), "+v"(a##S_##3) : "v"(base_), "v"(slot_));
-#else
 #define WD_READ_A(S_, base_, half_, slot_)                                                          \
     {                                                                                               \
         const float *As_r = (base_) + ((half_) * 8 + wave_m * 4) * 256 + (slot_) * 4;               \
@@ -628,29 +613,20 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         a##S_##2 = *reinterpret_cast<const f32x4 *>(As_r + 512);                                    \
         a##S_##3 = *reinterpret_cast<const f32x4 *>(As_r + 768);                                    \
     }
-#endif
 #define WD_MFMA_ROW(i_, av_, bv_, st_)                                                              \
     acc[i_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[0], acc[i_][0], 0, 0, 0);       \
     acc[i_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[1], acc[i_][1], 0, 0, 0);       \
     acc[i_][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[2], acc[i_][2], 0, 0, 0);       \
     acc[i_][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[st_], bv_[3], acc[i_][3], 0, 0, 0);
-#ifdef WIDE_DIAG_NO_MFMA                                    // timing aid (-DWIDE_DIAG_NO_MFMA): everything but the matrix instructions
-#define WD_MFMA_STEP(S_, st_) asm volatile("" :: "v"(a##S_##0), "v"(a##S_##1), "v"(a##S_##2), "v"(a##S_##3), "v"(b##S_##st_));
-#else
 #define WD_MFMA_STEP(S_, st_)                                                                       \
     WD_MFMA_ROW(0, a##S_##0, b##S_##st_, st_) WD_MFMA_ROW(1, a##S_##1, b##S_##st_, st_)             \
     WD_MFMA_ROW(2, a##S_##2, b##S_##st_, st_) WD_MFMA_ROW(3, a##S_##3, b##S_##st_, st_)
-#endif
     // Weight fragment of k step st of a half slice: W[ks * 32 + 16 half + 4q + st][column tile + 64 wave_n + 4r .. + 3],
     // 16 lanes on 256 consecutive bytes of each of four weight rows.
     const float *Wb;                                                // this lane's piece of k step 0 of the half being loaded
 #define WD_B_BASE(cur_, half_)                                                                      \
     Wb = ((cur_).side ? a.W_neigh : a.W_self) + (long long)((cur_).ks * WK + (half_) * 16 + 4 * q) * HH + (cur_).ct * WN + wave_n * 64 + 4 * r;
-#ifdef WIDE_DIAG_NO_B                                        // timing aid (-DWIDE_DIAG_NO_B): everything but the weight loads
-#define WD_LOAD_B(S_, st_) asm volatile("" : "+v"(b##S_##st_) : "v"(Wb));
-#else
 #define WD_LOAD_B(S_, st_) b##S_##st_ = *reinterpret_cast<const f32x4 *>(Wb + (st_) * HH);
-#endif
     // one k step of a half, then the reload of its weight register for the next slice
 #define WD_STEP(S_, st_) { WD_MFMA_STEP(S_, st_) __builtin_amdgcn_sched_barrier(0); WD_LOAD_B(S_, st_) __builtin_amdgcn_sched_barrier(0); }
 
@@ -681,9 +657,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         __builtin_amdgcn_sched_barrier(0);
         WD_B_BASE(cn, 1)
         WD_STEP(Y, 0) WD_STEP(Y, 1) WD_STEP(Y, 2) WD_STEP(Y, 3)
-#ifndef WIDE_DIAG_NO_EPILOGUE
         if (c.ks + 1 == (c.side ? sh.nn : sh.ns)) epilogue(c);
-#endif
         advance(c, sh, a);
         if (g + 2 < T) advance(cn, sh, a);
         stage = nstage;
