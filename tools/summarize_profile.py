@@ -73,6 +73,23 @@ if stats:
                 float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3))
     lines.append('')
 
+# a kernel launched on shapes of very different size: the average over its large launches (within a factor
+# four of the longest), which is what bench.py times for the dominant kernel
+traces = sorted(glob.glob(os.path.join(src, 'trace', '*', '*kernel_trace.csv')), key=os.path.getmtime, reverse=True)
+if traces:
+    dur = defaultdict(list)
+    for r in csv.DictReader(open(traces[0])):
+        if any(o in r['Kernel_Name'] for o in ours):
+            dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    mixed = {k: v for k, v in dur.items() if max(v) > 3.0 * min(v) and max(v) > 100.0}
+    if mixed:
+        lines += ['kernels launched on shapes of very different size, large launches only (within a factor four of the longest):', '',
+                  '| kernel | large launches | avg us | min us | max us |', '|---|---|---|---|---|']
+        for k, v in sorted(mixed.items()):
+            big = [x for x in v if x >= 0.25 * max(v)]
+            lines.append('| %s | %d of %d | %.2f | %.2f | %.2f |' % (k, len(big), len(v), sum(big) / len(big), min(big), max(big)))
+        lines.append('')
+
 traffic = {}
 for kind, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
     files = sorted(glob.glob(os.path.join(src, kind, '*', '*counter_collection.csv')), key=os.path.getmtime, reverse=True)
@@ -83,7 +100,10 @@ for kind, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
         if r.get('Counter_Name') == counter and any(o in r['Kernel_Name'] for o in ours):
             acc[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
     for k, v in acc.items():
-        traffic.setdefault(k, {})[kind] = (sum(v) / len(v) * 1024.0, len(v))
+        # a kernel launched on shapes of very different size (the wide kernel on layer 0 and on layer 1):
+        # the figure is that of its large launches, those within a factor four of the largest
+        big = [x for x in v if x >= 0.25 * max(v)]
+        traffic.setdefault(k, {})[kind] = (sum(big) / len(big) * 1024.0, len(big))
 if traffic:
     lines += ['## HBM-side traffic per launch (rocprofv3 --pmc, separate passes)', '',
               '| kernel | launches | FETCH_SIZE raw MB (requests x 64 B) | factor | read MB | WRITE_SIZE MB |',
@@ -93,7 +113,7 @@ if traffic:
         w, _ = d.get('write', (0.0, 0))
         lines.append('| %s | %d | %.2f | x%d | %.2f | %.2f |' % (k, nf, f / 1e6, fetch_factor(k), fetch_factor(k) * f / 1e6, w / 1e6))
     lines += ['', 'factor x2: 16-byte-per-lane row streams (128-byte requests tallied at 64 bytes); x1: scattered word reads, '
-              'the figure is the sectors they cost.', '']
+              'the figure is the sectors they cost.  Launches: those within a factor four of the kernel\'s largest.', '']
 sq_files = sorted(glob.glob(os.path.join(src, 'sq', '*', '*counter_collection.csv')), key=os.path.getmtime, reverse=True)
 if sq_files:
     # per kernel: the launch with the most wave cycles (the largest shape of that kernel)
