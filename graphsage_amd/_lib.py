@@ -97,7 +97,12 @@ class SageWeights(_c.Structure):
 class Sage2Saved(_c.Structure):
     """gs_sage2_saved of include/gsage.h."""
     _fields_ = [('x_self', _vp * 2), ('x_mean', _vp * 2), ('h1', _vp * 2), ('x_mean1', _vp * 2), ('z', _vp * 2),
-                ('self_ids', _vp * 2)]
+                ('self_ids', _vp * 2), ('h1_mask', _vp * 2)]
+
+
+class Sage2L0Mask(_c.Structure):
+    """gs_sage2_l0_mask of include/gsage.h."""
+    _fields_ = [('h1', _vp * 2), ('h1_mask', _vp * 2)]
 
 
 SIGNATURES['gs_sage2_supported'] = (_i32, [_i32] * 6)
@@ -107,13 +112,14 @@ SIGNATURES['gs_sage2_forward'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _
                                          _c.POINTER(SageWeights), _c.POINTER(SageWeights),
                                          _i32, _i32, _i32, _vp, _vp, _vp, _c.POINTER(Sage2Saved), _vp, _vp])
 SIGNATURES['gs_sage2_backward_tail'] = (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
-                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(Sage2L0Mask), _vp])
 
 SIGNATURES['gs_sage_project_wgrad_by_id_supported'] = (_i32, [_i32, _i32, _i32])
 SIGNATURES['gs_sage2_tail_head_workspace'] = (_sz, [_i64, _i32])
 SIGNATURES['gs_sage2_tail_head_rows'] = (_i32, [_i64])
 SIGNATURES['gs_sage2_backward_tail_head'] = (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
-                                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp])
+                                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                                    _c.POINTER(Sage2L0Mask), _vp])
 SIGNATURES['gs_link_head_reduce'] = (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp])
 _f32 = _c.c_float
 SIGNATURES['gs_link_head_workspace'] = (_sz, [_i64, _i32])

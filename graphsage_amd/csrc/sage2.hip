@@ -61,6 +61,7 @@ struct Sage2Args {
     float *sv_x_self[2], *sv_x_mean[2], *sv_h1[2];
     float *sv_x_mean1[2], *sv_z[2];                   // n_pairs rows: layer-1 neighbor mean, pre-norm output
     int32_t *sv_self_ids[2];                          // same rows as sv_x_self: the node id instead of its feature row
+    uint32_t *sv_h1_mask[2];                          // n_pairs * n0 * H1/32 words: [h1 > 0] of the hop-1 heads, instead of their rows
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -429,9 +430,30 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             // layer-0 activations: the root's row, then the hop-1 heads' rows as one contiguous block (LDH == H1)
             if (lane < H1V)
                 stream_store(a.sv_h1[side] + (size_t)pair * H1 + 4 * lane, *reinterpret_cast<const float4 *>(H1t + 4 * lane));
-            float *dst = a.sv_h1[1 - side] + (size_t)sv_h1row * H1;
-            for (int i = lane; i < n0 * H1V; i += 64)
-                stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(H1t + LDH + 4 * i));
+            if (a.sv_h1_mask[1 - side]) {
+                // the hop-1 heads' activations are read back only for their relu mask: one bit per element,
+                // 64 / H1 rows per ballot (lane = row * H1 + column: the ballot's words are the rows' words)
+                constexpr int RPB = 64 / H1;
+                uint32_t *mw = a.sv_h1_mask[1 - side] + (size_t)pair * n0 * (H1 / 32);
+                for (int j0 = 0; j0 < n0; j0 += RPB) {
+                    const int j = j0 + lane / H1;
+                    const bool on = j < n0 && H1t[(1 + min(j, n0 - 1)) * LDH + lane % H1] > 0.f;
+                    const unsigned long long bits = __ballot(on);
+                    if (lane == 0) {
+                        if (H1 == 32) {
+                            mw[j0] = (uint32_t)bits;
+                            if (j0 + 1 < n0) mw[j0 + 1] = (uint32_t)(bits >> 32);
+                        } else {
+                            mw[2 * j0] = (uint32_t)bits;
+                            mw[2 * j0 + 1] = (uint32_t)(bits >> 32);
+                        }
+                    }
+                }
+            } else {
+                float *dst = a.sv_h1[1 - side] + (size_t)sv_h1row * H1;
+                for (int i = lane; i < n0 * H1V; i += 64)
+                    stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(H1t + LDH + 4 * i));
+            }
         }
         wave_lds_fence();
         f32x4 acc_s[NT2], acc_n[NT2];
@@ -649,7 +671,10 @@ extern "C" int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, i
                 return gs::fail(GS_EINVAL, "gs_sage2_forward: saved-activation buffers must be 16-byte aligned");
             a.sv_x_self[t] = saved->x_self[t]; a.sv_x_mean[t] = saved->x_mean[t]; a.sv_h1[t] = saved->h1[t];
             a.sv_x_mean1[t] = saved->x_mean1[t]; a.sv_z[t] = saved->z[t];
+            a.sv_h1_mask[t] = saved->h1_mask[t];
         }
+        if (!saved->h1_mask[0] != !saved->h1_mask[1])
+            return gs::fail(GS_EINVAL, "gs_sage2_forward: h1_mask must be given for both node types or for none");
     }
     hipStream_t s = (hipStream_t)stream;
     const int hh1 = H1 / 2, hh2 = H2 / 2;

@@ -34,6 +34,9 @@ struct TailArgs {
     // HEAD: the link head and its loss in the same launch (g_emb is then not read)
     const float *emb[2], *head_kernel, *head_bias, *targets;
     float *pred, *head_slab;
+    // layer-0 relu masks (or NULL): the roots' saved layer-0 outputs, the hop-1 heads' mask words
+    const float *h1[2];
+    const uint32_t *h1_mask[2];
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -135,7 +138,10 @@ void sage2_tail_bwd_kernel(const TailArgs a) {
             ds = fmaf(gz_s[n], ws[n * H1 + k], ds);
             dn = fmaf(gz_s[HH2 + n], wn[n * H1 + k], dn);
         }
-        if (lane < H1) a.g_h1[t][p * H1 + lane] = ds;
+        if (lane < H1) {
+            if (a.h1[t] && !(a.h1[t][p * H1 + lane] > 0.f)) ds = 0.f;     // through layer 0's activation
+            a.g_h1[t][p * H1 + lane] = ds;
+        }
         // the n0 hop-1 heads of this walk: n0 * H1 consecutive floats repeating the H1 values dn / n0.  Stored
         // 16 bytes per lane: the values go through the wave's LDS line so that a lane holds columns 4*lane .. +3
         // (mod H1), which is what every one of its stores needs (256 is a multiple of H1)
@@ -145,7 +151,21 @@ void sage2_tail_bwd_kernel(const TailArgs a) {
         const f32x4 v4 = *reinterpret_cast<const f32x4 *>(gz_s + ((4 * lane) & (H1 - 1)));
         f32x4 *dst = reinterpret_cast<f32x4 *>(a.g_h1[o] + (a.n_pairs + p * a.n0) * H1);
         const int span4 = a.n0 * (H1 / 4);
-        for (int i = lane; i < span4; i += 64) dst[i] = v4;
+        if (a.h1_mask[o]) {
+            // element 4 i of the walk's n0 * H1 block: word (4 i) / 32, bits (4 i) % 32 .. + 3
+            const uint32_t *mw = a.h1_mask[o] + (size_t)p * a.n0 * (H1 / 32);
+            for (int i = lane; i < span4; i += 64) {
+                const uint32_t bits = mw[i >> 3] >> ((i & 7) * 4);
+                f32x4 m = v4;
+                if (!(bits & 1u)) m[0] = 0.f;
+                if (!(bits & 2u)) m[1] = 0.f;
+                if (!(bits & 4u)) m[2] = 0.f;
+                if (!(bits & 8u)) m[3] = 0.f;
+                dst[i] = m;
+            }
+        } else {
+            for (int i = lane; i < span4; i += 64) dst[i] = v4;
+        }
         wave_lds_fence();                                         // gz_s is rewritten by the next walk
     }
     if (HEAD) {
@@ -184,6 +204,16 @@ int launch_tail(const TailArgs &a, bool head, hipStream_t s) {
     return gs::check_launch(head ? "gs_sage2_backward_tail_head" : "gs_sage2_backward_tail");
 }
 
+int set_l0_mask(TailArgs &a, const gs_sage2_l0_mask *m, const char *who) {
+    if (!m) return GS_OK;
+    for (int t = 0; t < 2; ++t) {
+        if (!m->h1[t] || !m->h1_mask[t]) return gs::fail(GS_EINVAL, "%s: l0_mask has a null pointer", who);
+        a.h1[t] = m->h1[t];
+        a.h1_mask[t] = m->h1_mask[t];
+    }
+    return GS_OK;
+}
+
 }  // namespace
 
 extern "C" int gs_sage2_backward_tail(const float *z_user, const float *z_item,
@@ -192,7 +222,7 @@ extern "C" int gs_sage2_backward_tail(const float *z_user, const float *z_item,
                                       const float *w1_self_user, const float *w1_neigh_user,
                                       const float *w1_self_item, const float *w1_neigh_item,
                                       float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
-                                      void *stream) {
+                                      const gs_sage2_l0_mask *l0_mask, void *stream) {
     if (n_pairs < 0 || n0 < 1) return gs::fail(GS_EINVAL, "gs_sage2_backward_tail: n_pairs=%lld n0=%d", (long long)n_pairs, n0);
     if ((H1 != 32 && H1 != 64) || (H2 != 32 && H2 != 64))
         return gs::fail(GS_ELIMIT, "gs_sage2_backward_tail: H1=%d H2=%d (each 32 or 64: the widths of gs_sage2_forward)", H1, H2);
@@ -209,6 +239,7 @@ extern "C" int gs_sage2_backward_tail(const float *z_user, const float *z_item,
     a.w_self[0] = w1_self_user; a.w_neigh[0] = w1_neigh_user; a.w_self[1] = w1_self_item; a.w_neigh[1] = w1_neigh_item;
     a.g_z[0] = g_z_user; a.g_z[1] = g_z_item; a.g_h1[0] = g_h1_user; a.g_h1[1] = g_h1_item;
     a.n_pairs = n_pairs; a.n0 = n0; a.H1 = H1; a.H2 = H2; a.normalize = normalize != 0; a.relu = act == GS_ACT_RELU;
+    if (int rc = set_l0_mask(a, l0_mask, "gs_sage2_backward_tail")) return rc;
     return launch_tail(a, false, (hipStream_t)stream);
 }
 
@@ -226,7 +257,8 @@ extern "C" int gs_sage2_backward_tail_head(const float *z_user, const float *z_i
                                            const float *w1_self_user, const float *w1_neigh_user,
                                            const float *w1_self_item, const float *w1_neigh_item,
                                            float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
-                                           float *pred, void *head_slab, size_t head_slab_bytes, void *stream) {
+                                           float *pred, void *head_slab, size_t head_slab_bytes,
+                                           const gs_sage2_l0_mask *l0_mask, void *stream) {
     if (n_pairs < 1 || n0 < 1) return gs::fail(GS_EINVAL, "gs_sage2_backward_tail_head: n_pairs=%lld n0=%d", (long long)n_pairs, n0);
     if ((H1 != 32 && H1 != 64) || (H2 != 32 && H2 != 64))
         return gs::fail(GS_ELIMIT, "gs_sage2_backward_tail_head: H1=%d H2=%d (each 32 or 64: the widths of gs_sage2_forward)", H1, H2);
@@ -248,5 +280,6 @@ extern "C" int gs_sage2_backward_tail_head(const float *z_user, const float *z_i
     a.n_pairs = n_pairs; a.n0 = n0; a.H1 = H1; a.H2 = H2; a.normalize = normalize != 0; a.relu = act == GS_ACT_RELU;
     a.emb[0] = emb_user; a.emb[1] = emb_item; a.head_kernel = head_kernel; a.head_bias = head_bias; a.targets = targets;
     a.pred = pred; a.head_slab = static_cast<float *>(head_slab);
+    if (int rc = set_l0_mask(a, l0_mask, "gs_sage2_backward_tail_head")) return rc;
     return launch_tail(a, true, (hipStream_t)stream);
 }

@@ -462,10 +462,29 @@ class WgradPairCall:
                                                    *self._args, stream_handle()), 'gs_sage_project_wgrad_pair')
 
 
-def sage2_backward_tail(z, g_emb, w1_self, w1_neigh, n0, normalize, act, g_z, g_h1):
+def _l0_mask_struct(l0_mask, b, n0, h1):
+    """gs_sage2_l0_mask from {'h1': {type: (>= B, H1) float32}, 'h1_mask': {type: int32 words}}, or None."""
+    if l0_mask is None:
+        return None, None
+    st = _lib.Sage2L0Mask()
+    for i, t in enumerate(('user', 'item')):
+        rows, words = l0_mask['h1'][t], l0_mask['h1_mask'][t]
+        _dev(rows, torch.float32, 'l0_mask[h1][%s]' % t, 2)
+        _dev(words, torch.int32, 'l0_mask[h1_mask][%s]' % t, 1)
+        if rows.shape[0] < b or rows.shape[1] != h1:
+            raise ValueError("l0_mask[h1][%s] must hold at least %d rows of %d" % (t, b, h1))
+        if words.numel() != b * int(n0) * (h1 // 32):
+            raise ValueError("l0_mask[h1_mask][%s] must have %d words" % (t, b * int(n0) * (h1 // 32)))
+        st.h1[i] = rows.data_ptr()
+        st.h1_mask[i] = words.data_ptr()
+    return st, ctypes.byref(st)
+
+
+def sage2_backward_tail(z, g_emb, w1_self, w1_neigh, n0, normalize, act, g_z, g_h1, l0_mask=None):
     """``gs_sage2_backward_tail``: every argument but the scalars is a dict by node
     type.  ``z`` / ``g_emb`` / ``g_z`` are (B, H2), ``w1_*`` (H1, H2/2), ``g_h1``
-    (B * (1 + n0), H1) in the row layout of the one-kernel forward's saved tables."""
+    (B * (1 + n0), H1) in the row layout of the one-kernel forward's saved tables.
+    ``l0_mask``: the layer-0 relu masks (see ``_l0_mask_struct``); ``g_h1`` then leaves masked."""
     lib = load()
     types = ('user', 'item')
     b, h2 = z['user'].shape
@@ -481,11 +500,11 @@ def sage2_backward_tail(z, g_emb, w1_self, w1_neigh, n0, normalize, act, g_z, g_
                                      b, int(n0), h1, h2, int(bool(normalize)), ACT[act],
                                      ptr(w1_self['user']), ptr(w1_neigh['user']), ptr(w1_self['item']), ptr(w1_neigh['item']),
                                      ptr(g_z['user']), ptr(g_z['item']), ptr(g_h1['user']), ptr(g_h1['item']),
-                                     stream_handle()), 'gs_sage2_backward_tail')
+                                     _l0_mask_struct(l0_mask, b, n0, h1)[1], stream_handle()), 'gs_sage2_backward_tail')
 
 
 def sage2_backward_tail_head(z, emb, targets, head_kernel, head_bias, w1_self, w1_neigh, n0, normalize, act,
-                             g_z, g_h1, pred, slab):
+                             g_z, g_h1, pred, slab, l0_mask=None):
     """``gs_sage2_backward_tail_head``: ``sage2_backward_tail`` with the link head and its
     loss inside; ``emb`` = {'user','item'} embeddings (B, H2), ``slab`` the float32 workspace
     that ``link_head_reduce`` turns into the head's gradients and the loss."""
@@ -509,7 +528,8 @@ def sage2_backward_tail_head(z, emb, targets, head_kernel, head_bias, w1_self, w
                                           ptr(head_kernel), ptr(head_bias), b, int(n0), h1, h2, int(bool(normalize)), ACT[act],
                                           ptr(w1_self['user']), ptr(w1_neigh['user']), ptr(w1_self['item']), ptr(w1_neigh['item']),
                                           ptr(g_z['user']), ptr(g_z['item']), ptr(g_h1['user']), ptr(g_h1['item']),
-                                          ptr(pred), ptr(slab), slab.numel() * 4, stream_handle()),
+                                          ptr(pred), ptr(slab), slab.numel() * 4,
+                                          _l0_mask_struct(l0_mask, b, n0, h1)[1], stream_handle()),
           'gs_sage2_backward_tail_head')
 
 
@@ -762,6 +782,13 @@ class Sage2Call:
                     if tuple(buf.shape) != shape(t):
                         raise ValueError("saved[%s][%s] must be %s (got %s)" % (name, t, shape(t), tuple(buf.shape)))
                     getattr(st, name)[i] = buf.data_ptr()
+            if saved.get('h1_mask') is not None:           # relu masks of the hop-1 heads instead of their h1 rows
+                for i, t in enumerate(('user', 'item')):
+                    buf = saved['h1_mask'][t]
+                    _dev(buf, torch.int32, 'saved[h1_mask][%s]' % t, 1)
+                    if buf.numel() != self.n_pairs * n0 * (h1 // 32):
+                        raise ValueError("saved[h1_mask][%s] must have %d words" % (t, self.n_pairs * n0 * (h1 // 32)))
+                    st.h1_mask[i] = buf.data_ptr()
             self._saved = st
         self._lib = lib
         self._keep = [indptr, indices, feat_user, feat_item, weights, saved]

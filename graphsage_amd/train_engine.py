@@ -76,6 +76,13 @@ class SageTrainEngine(SageForwardEngine):
         if (self._tail_kernel and f['user'] == f['item'] and
                 kernels.load().gs_sage_project_wgrad_by_id_supported(f['user'], f['item'], m.dims[1]['user'])):
             self.self_ids = {t: torch.zeros(self.h[0][t].shape[0], dtype=torch.int32, device=dev) for t in _TYPES}
+        # The hop-1 heads' layer-0 outputs are read back only for their relu mask (their values reach layer 1
+        # through the saved neighbor mean): the forward kernel leaves one bit per element instead of the rows,
+        # the top-of-backward kernel applies the masks, and the layer-0 weight gradients take its output as it is.
+        self.h1_mask = None
+        if self._tail_kernel and all(m._aggs[0][t].activation == 'relu' for t in _TYPES):
+            words = self.batch * self.fanouts[0] * (m.dims[1]['user'] // 32)
+            self.h1_mask = {t: torch.zeros(words, dtype=torch.int32, device=dev) for t in _TYPES}
         self._head_slab = None
 
     @property
@@ -87,8 +94,9 @@ class SageTrainEngine(SageForwardEngine):
         """Switching the one-launch top of the backward pass off (comparisons, tests) also brings back
         the gathered copy of the own rows, which the layer-by-layer backward kernels read."""
         self._tail_kernel = bool(on) and self.walk_train
-        if not self._tail_kernel and self.self_ids is not None:
+        if not self._tail_kernel and (self.self_ids is not None or self.h1_mask is not None):
             self.self_ids = None
+            self.h1_mask = None
             self._walk_train_call = None
             self._wgrad_pairs = None
 
@@ -103,6 +111,8 @@ class SageTrainEngine(SageForwardEngine):
             if self.self_ids is not None:
                 saved['self_ids'] = self.self_ids
                 del saved['x_self']
+            if self.h1_mask is not None:
+                saved['h1_mask'] = self.h1_mask
             self._walk_train_call = kernels.Sage2Call(
                 self.indptr, self.indices, self.tables['user'][0], self.tables['item'][0], self.fanouts, weights,
                 m.normalize == "l2", self.batch, emb=self.emb_all, saved=saved)
@@ -216,10 +226,12 @@ class SageTrainEngine(SageForwardEngine):
         if self._side2 is None:
             self._side2 = torch.cuda.Stream()
         top = m._aggs[1]
+        l0_mask = None if self.h1_mask is None else {'h1': self.h[0], 'h1_mask': self.h1_mask}
         if head is None:
             kernels.sage2_backward_tail(self.z, {'user': g_user.contiguous(), 'item': g_item.contiguous()},
                                         {t: top[t].w_self for t in _TYPES}, {t: top[t].w_neigh for t in _TYPES},
-                                        self.fanouts[0], m.normalize == "l2", top['user'].activation, self.g_z, self.g_h[0])
+                                        self.fanouts[0], m.normalize == "l2", top['user'].activation, self.g_z, self.g_h[0],
+                                        l0_mask=l0_mask)
         else:
             head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss = head
             if self._head_slab is None:
@@ -228,7 +240,7 @@ class SageTrainEngine(SageForwardEngine):
                                              targets, head_kernel, head_bias,
                                              {t: top[t].w_self for t in _TYPES}, {t: top[t].w_neigh for t in _TYPES},
                                              self.fanouts[0], m.normalize == "l2", top['user'].activation,
-                                             self.g_z, self.g_h[0], pred, self._head_slab)
+                                             self.g_z, self.g_h[0], pred, self._head_slab, l0_mask=l0_mask)
         f = {t: self.x_self[t].shape[1] for t in _TYPES}
         if f['user'] == f['item']:
             # both node types of a layer have one shape: each layer's weight gradients are one launch (+ one
@@ -273,11 +285,15 @@ class SageTrainEngine(SageForwardEngine):
                 p.grad = torch.zeros_like(p)
         return agg.w_self.grad, agg.w_neigh.grad, None if agg.bias is None else agg.bias.grad
 
+    def _wgrad_act(self, layer, t):
+        """Activation the weight-gradient kernels apply: none where the gradient arrives masked already."""
+        return 'linear' if layer == 0 and self.h1_mask is not None else self.model._aggs[layer][t].activation
+
     def _weight_grads(self, layer, t):
         agg = self.model._aggs[layer][t]
         x_self, x_mean, out, g_out = self._wgrad_inputs(layer, t)
         g_ws, g_wn, g_b = self._grads_of(agg)
-        kernels.sage_project_bwd(x_self, x_mean, agg.w_self, agg.w_neigh, agg.activation, out, g_out,
+        kernels.sage_project_bwd(x_self, x_mean, agg.w_self, agg.w_neigh, self._wgrad_act(layer, t), out, g_out,
                                  need_x_self=False, need_x_mean=False, need_bias=g_b is not None,
                                  g_w_self=g_ws, g_w_neigh=g_wn, g_bias=g_b, workspace=self.ws[layer][t])
 
@@ -287,12 +303,12 @@ class SageTrainEngine(SageForwardEngine):
             agg = self.model._aggs[layer][t]
             x_self, x_mean, out, g_out = self._wgrad_inputs(layer, t)
             g_ws, g_wn, g_b = self._grads_of(agg)
-            prob = {'x_self': x_self, 'x_mean': x_mean, 'out': out, 'g_out': g_out, 'g_w_self': g_ws,
-                    'g_w_neigh': g_wn, 'g_bias': g_b, 'workspace': self.ws[layer][t]}
+            prob = {'x_self': x_self, 'x_mean': x_mean, 'out': out if self._wgrad_act(layer, t) == 'relu' else None,
+                    'g_out': g_out, 'g_w_self': g_ws, 'g_w_neigh': g_wn, 'g_bias': g_b, 'workspace': self.ws[layer][t]}
             if layer == 0 and self.self_ids is not None:    # own rows from the feature table, by the saved ids
                 prob.update(x_self=self.tables[t][0], self_ids=self.self_ids[t], self_off=self.tables[t][1])
             problems.append(prob)
-        return kernels.WgradPairCall(problems, self.model._aggs[layer]['user'].activation)
+        return kernels.WgradPairCall(problems, self._wgrad_act(layer, 'user'))
 
     def backward(self, g_user, g_item):
         """Gradients of every aggregator weight from the embedding gradients; they

@@ -420,6 +420,11 @@ typedef struct gs_sage2_saved {
     float *z[2];
     int32_t *self_ids[2];   /* nullable: [rows] the node id of each row of x_self (4 bytes instead of a feature row;
                                gs_sage_project_wgrad_pair reads the rows from the table by these ids) */
+    uint32_t *h1_mask[2];   /* nullable, both or none: [n_pairs * n0 * H1/32] words.  The hop-1 heads' rows of h1 (rows
+                               n_pairs ..) are read back only for their relu mask (their values enter layer 1 through
+                               x_mean1), so with h1_mask they are NOT written; bit c % 32 of word
+                               (row - n_pairs) * H1/32 + c / 32 says whether h1[row, c] > 0.  gs_sage2_backward_tail
+                               applies these masks (its l0_mask argument) */
 } gs_sage2_saved;
 
 int gs_sage2_supported(int Fu, int Fi, int H1, int H2, int n0, int n1);
@@ -434,6 +439,18 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
                      int H1, int H2, int normalize,
                      float *emb, int32_t *out_hop1, int32_t *out_hop2,
                      const gs_sage2_saved *saved, int32_t *err_flag, void *stream);
+
+/*
+ * The layer-0 relu masks for gs_sage2_backward_tail / gs_sage2_backward_tail_head (their nullable l0_mask argument), in which case g_h1 leaves as the
+ * gradient at the layer-0 PRE-activations (g_h1 * [h1 > 0]) and the layer-0 weight gradients take it with
+ * act = linear, without reading the forward output again:
+ *   h1[t]       [>= n_pairs, H1]  rows of the roots: the saved layer-0 outputs themselves
+ *   h1_mask[t]  the mask words gs_sage2_forward wrote for the hop-1 heads (gs_sage2_saved.h1_mask)
+ */
+typedef struct gs_sage2_l0_mask {
+    const float *h1[2];
+    const uint32_t *h1_mask[2];
+} gs_sage2_l0_mask;
 
 /*
  * Backward of the top of that model, one launch for both node types: from the
@@ -460,7 +477,7 @@ int gs_sage2_backward_tail(const float *z_user, const float *z_item,
                            const float *w1_self_user, const float *w1_neigh_user,
                            const float *w1_self_item, const float *w1_neigh_item,
                            float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
-                           void *stream);
+                           const gs_sage2_l0_mask *l0_mask, void *stream);
 
 /*
  * gs_sage2_backward_tail with the link head and its loss evaluated in the same
@@ -484,7 +501,7 @@ int gs_sage2_backward_tail_head(const float *z_user, const float *z_item,
                                 const float *w1_self_user, const float *w1_neigh_user,
                                 const float *w1_self_item, const float *w1_neigh_item,
                                 float *g_z_user, float *g_z_item, float *g_h1_user, float *g_h1_item,
-                                float *pred, void *head_slab, size_t head_slab_bytes, void *stream);
+                                float *pred, void *head_slab, size_t head_slab_bytes, const gs_sage2_l0_mask *l0_mask, void *stream);
 int gs_link_head_reduce(const void *slab, int n_rows, int E, int64_t B, float *g_kernel, float *g_bias,
                         float *loss, void *stream);
 

@@ -43,7 +43,7 @@ int main() {
     int64_t *i64 = reinterpret_cast<int64_t *>(arena + 2048);
     float *odd = reinterpret_cast<float *>(arena + 4);           // not 16-byte aligned
 
-    EXPECT(gs_version() >= 2);
+    EXPECT(gs_version() >= 3);
     EXPECT(gs_last_error() != nullptr);
 
     // ---- timers (no event is created here: that needs a device) ----
@@ -232,24 +232,31 @@ int main() {
     REFUSED(GS_EINVAL, gs_sage2_forward(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 25, 10, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, 1, f, nullptr, nullptr, &sv, i32, nullptr));   // neither own rows nor ids
     sv.self_ids[0] = sv.self_ids[1] = i32; sv.x_mean[1] = odd;
     REFUSED(GS_EINVAL, gs_sage2_forward(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 25, 10, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, 1, f, nullptr, nullptr, &sv, i32, nullptr));
+    sv.x_mean[1] = f; sv.h1_mask[0] = reinterpret_cast<uint32_t *>(i32);          // mask words for one node type only
+    REFUSED(GS_EINVAL, gs_sage2_forward(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 25, 10, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, 1, f, nullptr, nullptr, &sv, i32, nullptr));
 
     // ---- top of the backward pass ----
-    ACCEPTED(gs_sage2_backward_tail(f, f, f, f, 0, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr));
-    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, -1, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr));
-    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, 8, 0, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr));
-    REFUSED(GS_ELIMIT, gs_sage2_backward_tail(f, f, f, f, 8, 25, 48, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr));
-    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, 8, 25, 32, 32, 1, 5, f, f, f, f, f, f, f, f, nullptr));
-    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, nullptr, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr));
-    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, odd, f, nullptr));
-    REFUSED(GS_ELIMIT, gs_sage2_backward_tail(f, f, f, f, (int64_t)1 << 39, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr));
+    ACCEPTED(gs_sage2_backward_tail(f, f, f, f, 0, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));
+    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, -1, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));
+    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, 8, 0, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));
+    REFUSED(GS_ELIMIT, gs_sage2_backward_tail(f, f, f, f, 8, 25, 48, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));
+    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, 8, 25, 32, 32, 1, 5, f, f, f, f, f, f, f, f, nullptr, nullptr));
+    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, nullptr, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));
+    REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, odd, f, nullptr, nullptr));
+    REFUSED(GS_ELIMIT, gs_sage2_backward_tail(f, f, f, f, (int64_t)1 << 39, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));
+    {
+        gs_sage2_l0_mask lm{};                                  // a mask set with a missing pointer
+        lm.h1[0] = lm.h1[1] = f; lm.h1_mask[0] = reinterpret_cast<const uint32_t *>(f);
+        REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, &lm, nullptr));
+    }
     EXPECT(gs_sage2_tail_head_workspace(-1, 32) == 0);
     EXPECT(gs_sage2_tail_head_rows(1) == 1 && gs_sage2_tail_head_rows(4096) == 256 && gs_sage2_tail_head_rows((int64_t)1 << 40) == 256);
     const size_t th = gs_sage2_tail_head_workspace(4096, 32);
     EXPECT(th == (size_t)256 * 66 * 4);
-    REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, f, f, f, 0, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr));
-    REFUSED(GS_ELIMIT, gs_sage2_backward_tail_head(f, f, f, f, f, f, f, 8, 25, 32, 128, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr));
-    REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, nullptr, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr));
-    REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, f, f, f, 4096, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th - 4, nullptr));
+    REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, f, f, f, 0, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr, nullptr));
+    REFUSED(GS_ELIMIT, gs_sage2_backward_tail_head(f, f, f, f, f, f, f, 8, 25, 32, 128, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr, nullptr));
+    REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, nullptr, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr, nullptr));
+    REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, f, f, f, 4096, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th - 4, nullptr, nullptr));
 
     // ---- link head, optimizer, staging ----
     EXPECT(gs_link_head_workspace(-1, 32) == 0 && gs_link_head_workspace(4096, 32) == (size_t)256 * 66 * 4);

@@ -403,6 +403,70 @@ def test_backward_tail_kernel_equals_the_layer_by_layer_kernels(cuda, b, n0, h1,
     assert not any(bool(torch.isnan(g_h1[t]).any()) for t in types)   # every row written
 
 
+def _pack_mask(h):
+    """[rows, H] > 0 packed the way gs_sage2_forward packs it: bit c % 32 of word row * H/32 + c / 32."""
+    bits = (h > 0).to(torch.int64).reshape(h.shape[0], h.shape[1] // 32, 32)
+    words = (bits << torch.arange(32, device=h.device)).sum(-1)
+    return (words & 0xFFFFFFFF).to(torch.int64)
+
+
+@pytest.mark.parametrize('b,n0,n1,f,h1,h2', [(24, 8, 4, 64, 32, 32), (9, 25, 10, 64, 64, 32), (130, 3, 2, 64, 32, 64)])
+def test_saving_forward_writes_relu_mask_words_and_the_tail_kernel_applies_them(cuda, b, n0, n1, f, h1, h2):
+    """gs_sage2_saved.h1_mask: the hop-1 heads' layer-0 outputs leave as one bit per element (and their
+    rows are not written); everything else the forward saves is unchanged.  gs_sage2_backward_tail with
+    l0_mask = its plain output times the layer-0 relu masks."""
+    from graphsage_amd import kernels
+    g, links, _ = _toy(3, fu=f, fi=f)
+    dev_t = g.device_tensors()
+    gen = torch.Generator(device=cuda).manual_seed(b + n0)
+    rnd = lambda *shape: torch.randn(shape, device=cuda, generator=gen)
+    types = ('user', 'item')
+    weights = {}
+    for t in types:
+        weights[(0, t)] = (rnd(f, h1 // 2) * 0.2, rnd(f, h1 // 2) * 0.2, rnd(h1) * 0.1)
+        weights[(1, t)] = (rnd(h1, h2 // 2) * 0.2, rnd(h1, h2 // 2) * 0.2, rnd(h2) * 0.1)
+    lk = np.asarray(links[:b])
+    seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+    walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda)
+    err = torch.zeros(2, dtype=torch.int32, device=cuda)
+    rows = b * (1 + n0)
+
+    def tables():
+        nan = lambda *shape: torch.full(shape, float('nan'), device=cuda)
+        return {'x_self': {t: nan(rows, f) for t in types}, 'x_mean': {t: nan(rows, f) for t in types},
+                'h1': {t: nan(rows, h1) for t in types}, 'x_mean1': {t: nan(b, h1) for t in types},
+                'z': {t: nan(b, h2) for t in types}}
+    full, lean = tables(), tables()
+    lean['h1_mask'] = {t: torch.full((b * n0 * (h1 // 32),), -1, dtype=torch.int32, device=cuda) for t in types}
+    outs = []
+    for saved in (full, lean):
+        call = kernels.Sage2Call(dev_t['indptr'], dev_t['indices'], dev_t['user'], dev_t['item'], [n0, n1], weights,
+                                 True, b, saved=saved)
+        outs.append(call.run(seeds, err, rng_seed=4, walk_ids=walk_ids).clone())
+    assert err.tolist() == [0, 0] and torch.equal(outs[0], outs[1])
+    for t in types:
+        for name in ('x_self', 'x_mean', 'x_mean1', 'z'):
+            assert torch.equal(full[name][t], lean[name][t])
+        assert torch.equal(full['h1'][t][:b], lean['h1'][t][:b])                 # the roots' rows: still values
+        assert bool(torch.isnan(lean['h1'][t][b:]).all())                        # the hop-1 heads' rows: not written
+        got = lean['h1_mask'][t].to(torch.int64) & 0xFFFFFFFF
+        assert torch.equal(got, _pack_mask(full['h1'][t][b:]).reshape(-1))
+        assert 0.05 < float((full['h1'][t][b:] > 0).float().mean()) < 0.95       # (masks that mean something)
+
+    z = full['z']
+    g_emb = {t: rnd(b, h2) for t in types}
+    ws, wn = {t: weights[(1, t)][0] for t in types}, {t: weights[(1, t)][1] for t in types}
+    plain = {t: torch.empty(rows, h1, device=cuda) for t in types}
+    masked = {t: torch.full((rows, h1), float('nan'), device=cuda) for t in types}
+    gz0, gz1 = ({t: torch.empty(b, h2, device=cuda) for t in types} for _ in range(2))
+    kernels.sage2_backward_tail(z, g_emb, ws, wn, n0, True, 'linear', gz0, plain)
+    kernels.sage2_backward_tail(z, g_emb, ws, wn, n0, True, 'linear', gz1, masked,
+                                l0_mask={'h1': lean['h1'], 'h1_mask': lean['h1_mask']})
+    for t in types:
+        assert torch.equal(gz0[t], gz1[t])
+        assert torch.equal(masked[t], plain[t] * (full['h1'][t] > 0))
+
+
 def test_plan_backward_with_and_without_the_tail_kernel(cuda):
     """A two-hop training step through the one-launch top of the backward pass and through the
     layer-by-layer kernels: same loss, same gradients."""
