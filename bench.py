@@ -408,23 +408,37 @@ def main():
             tr = None
             train = autograd_train_step(args, ga, gen, model, heads_u, heads_i, b, rank, world, dist, sync_dev, device,
                                         "static plan not available (%s)" % str(ex)[:120])
-        if tr is not None:
+        def timed_training():
             tgt = (torch.arange(b, device=device) % 2).to(torch.float32)
 
             # the step's launches are replayed from a captured HIP graph; with several GPUs the graph
             # ends after backward, the RCCL all-reduce and the update follow it on the stream
-            step_fn = tr.step_device if os.environ.get('BENCH_EAGER_TRAIN') else tr.step_graph
+            mode = {'fn': tr.step_device if os.environ.get('BENCH_EAGER_TRAIN') else tr.step_graph}
 
             def tstep(i):
                 k = my_batches[i % len(my_batches)]
-                return step_fn(seeds[k], tgt, walk_ids[k], rng_seed=gen.sampler.seed + 1)
+                return mode['fn'](seeds[k], tgt, walk_ids[k], rng_seed=gen.sampler.seed + 1)
 
-            for i in range(5):
-                tstep(i)
-                if os.environ.get('BENCH_DEBUG'):
-                    torch.cuda.synchronize()
-                    print('[r%d] train warm-up step %d done' % (rank, i), file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
+            def warm_up():
+                for i in range(5):
+                    tstep(i)
+                    if os.environ.get('BENCH_DEBUG'):
+                        torch.cuda.synchronize()
+                        print('[r%d] train warm-up step %d done' % (rank, i), file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+
+            try:
+                warm_up()
+            except Exception:
+                if mode['fn'] is tr.step_device:
+                    raise
+                # a capture that does not go through (every rank fails at the same place, before any
+                # collective of the step): the same step launch by launch
+                import traceback
+                traceback.print_exc()
+                print('[r%d] graph replay unavailable, timing the eager step' % rank, file=sys.stderr, flush=True)
+                mode['fn'] = tr.step_device
+                warm_up()
             if world > 1:
                 dist.barrier()
             t1 = time.perf_counter()
@@ -439,10 +453,23 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 t_el = float(tt.item())
             assert tr.engine.err_flag.tolist() == [0, 0]
-            train = {"value": args.train_steps * b * world / t_el, "unit": "seed edges/s",
-                     "ms_per_step": t_el / args.train_steps * 1e3, "steps": args.train_steps,
-                     "what": "sample + fwd + bwd + flat-bucket all-reduce (RCCL for N>1) + Adam, MSE on concat->Dense(1,sigmoid)"
-                             + ("" if os.environ.get('BENCH_EAGER_TRAIN') else "; launches replayed from a captured HIP graph")}
+            return {"value": args.train_steps * b * world / t_el, "unit": "seed edges/s",
+                    "ms_per_step": t_el / args.train_steps * 1e3, "steps": args.train_steps,
+                    "what": "sample + fwd + bwd + flat-bucket all-reduce (RCCL for N>1) + Adam, MSE on concat->Dense(1,sigmoid)"
+                            + ("" if mode['fn'] is tr.step_device else "; launches replayed from a captured HIP graph")}
+
+        if tr is not None:
+            try:
+                train = timed_training()
+            except Exception as ex:                          # the headline number must survive a failing training step
+                import traceback
+                traceback.print_exc()
+                guard.cancel()
+                if rank == 0:
+                    print(json.dumps(result_line(args, cfg, engine, world, b, fwd,
+                                                 {"skipped": "training step failed: %s" % str(ex)[:200]}, None, ranks_seen)),
+                          flush=True)
+                os._exit(3)                                  # (other ranks may sit in a collective this one left)
 
     guard.cancel()
     if rank == 0:
