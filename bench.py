@@ -15,6 +15,7 @@ from this script itself: ``python bench.py --gpus N`` starts N ranks and relays 
 
 Environment switches for comparisons: BENCH_UNFUSED=1 runs the forward pass on the
 general kernels (sample, gather-mean, projection) instead of the fused ones;
+BENCH_SUBTREE_KERNEL=1 runs three-hop workloads through the one-wavefront-per-subtree kernel;
 BENCH_DRAW_IN_LAYER=1 lets the layer-0 kernel of the layered routes draw the deepest hop
 itself (the sampler kernel then stops one hop short);
 BENCH_EAGER_TRAIN=1 launches the training step kernel by kernel instead of
@@ -339,7 +340,8 @@ def main():
     gen = ga.GraphSAGEGenerator(graph, b, cfg['fan'], head_node_types=['user', 'item'], seed=0x9E3779B97F4A7C15)
     model = ga.GraphSAGE(cfg['layers'], gen, seed=7).build()
     engine = SageForwardEngine(graph, model, b, use_fused=not os.environ.get('BENCH_UNFUSED'),
-                               draw_in_layer=bool(os.environ.get('BENCH_DRAW_IN_LAYER')))
+                               draw_in_layer=bool(os.environ.get('BENCH_DRAW_IN_LAYER')),
+                               subtree_kernel=bool(os.environ.get('BENCH_SUBTREE_KERNEL')))
     engine.static_weights = True         # inference: padded weight copies (odd feature widths) are made once
 
     # per-step inputs, resident in HBM: roots (sources then destinations) and the walk ids

@@ -100,6 +100,12 @@ class Sage2Saved(_c.Structure):
                 ('self_ids', _vp * 2), ('h1_mask', _vp * 2)]
 
 
+class Sage2Subtrees(_c.Structure):
+    """gs_sage2_subtrees of include/gsage.h."""
+    _fields_ = [('roots_per_walk', _i32), ('tape_len', _i64), ('tape_off_hop2', _i64), ('tape_off_hop3', _i64),
+                ('out_h0', _vp)]
+
+
 class Sage2L0Mask(_c.Structure):
     """gs_sage2_l0_mask of include/gsage.h."""
     _fields_ = [('h1', _vp * 2), ('h1_mask', _vp * 2)]
@@ -111,6 +117,11 @@ SIGNATURES['gs_sage2_forward'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _
                                          _c.POINTER(SageWeights), _c.POINTER(SageWeights),
                                          _c.POINTER(SageWeights), _c.POINTER(SageWeights),
                                          _i32, _i32, _i32, _vp, _vp, _vp, _c.POINTER(Sage2Saved), _vp, _vp])
+SIGNATURES['gs_sage2_forward_subtrees'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
+                                                  _u64, _u64, _vp, _vp,
+                                                  _c.POINTER(SageWeights), _c.POINTER(SageWeights),
+                                                  _c.POINTER(SageWeights), _c.POINTER(SageWeights),
+                                                  _i32, _i32, _vp, _vp, _vp, _c.POINTER(Sage2Subtrees), _vp, _vp])
 SIGNATURES['gs_sage2_backward_tail'] = (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
                                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(Sage2L0Mask), _vp])
 

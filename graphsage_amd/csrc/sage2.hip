@@ -62,6 +62,12 @@ struct Sage2Args {
     float *sv_x_mean1[2], *sv_z[2];                   // n_pairs rows: layer-1 neighbor mean, pre-norm output
     int32_t *sv_self_ids[2];                          // same rows as sv_x_self: the node id instead of its feature row
     uint32_t *sv_h1_mask[2];                          // n_pairs * n0 * H1/32 words: [h1 > 0] of the hop-1 heads, instead of their rows
+    // Subtree mode (sub_n > 0): root i is hop-1 node i % sub_n of seed walk i / sub_n of a deeper model, whose
+    // hops 1 and 2 this kernel draws (sampler hop = local hop + 1, slots shifted by the subtree's position);
+    // the item-typed roots come first (they hang below the user-rooted seed walks).
+    int sub_n, top_relu;
+    long long tape_len, tape_off0, tape_off1;         // replay tape: words per seed walk, offsets of local hops 0 / 1
+    float *out_h0;                                    // nullable: [roots, H1] layer-0 output of every root
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -207,17 +213,25 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     asm volatile("" : "+v"(wl));            // keeps the weight-fragment reads inside the walk loop
 
     // ---- sampling ---------------------------------------------------------------
-    if (root < 0 && lane == 0) atomicMax(&a.err[1], 1);    // the caller maps out-of-range roots to -1
-    const unsigned long long walk = a.walk_ids ? (unsigned long long)a.walk_ids[w] : a.walk_base + (unsigned long long)w;
+    // the caller maps out-of-range roots to -1, or to -2 where -1 itself is a legitimate entry (subtree roots
+    // below an isolated node, which the sampler has reported)
+    if (root < (a.sub_n ? -1 : 0) && lane == 0) atomicMax(&a.err[1], 1);
+    // seed walk and position below it (whole walks: the walk itself, position 0)
+    const long long seed_walk = a.sub_n ? w / a.sub_n : w;
+    const unsigned sub_j = a.sub_n ? (unsigned)(w - seed_walk * a.sub_n) : 0u;
+    const unsigned hop_base = a.sub_n ? 1u : 0u;
+    const unsigned slot0 = sub_j * (unsigned)n0, slot1 = sub_j * (unsigned)(n0 * n1);
+    const unsigned long long walk = a.walk_ids ? (unsigned long long)a.walk_ids[seed_walk] : a.walk_base + (unsigned long long)seed_walk;
     const unsigned wlo = (unsigned)walk, whi = (unsigned)(walk >> 32);
-    const uint32_t *tape = a.replay ? a.replay + (size_t)w * (n0 + n0 * n1) : nullptr;
+    const uint32_t *tape = a.replay ? a.replay + (size_t)seed_walk * a.tape_len : nullptr;
+    const uint32_t *tape0 = tape ? tape + a.tape_off0 + slot0 : nullptr, *tape1 = tape ? tape + a.tape_off1 + slot1 : nullptr;
     wave_lds_fence();                        // the previous walk's readers of s_ids / A / H1t are done
     {
         const uint32_t deg = (uint32_t)(rb - ra);
         if (root >= 0 && deg == 0 && lane == 0) atomicMax(&a.err[0], root + 1);
         const bool live = root >= 0 && deg != 0;
         for (int t = lane; t < n0; t += 64) {
-            const uint32_t rr = tape ? tape[t] : gs::philox4x32_10_x(wlo, whi, 0u, (uint32_t)t, a.key0, a.key1);
+            const uint32_t rr = tape ? tape0[t] : gs::philox4x32_10_x(wlo, whi, hop_base, slot0 + (uint32_t)t, a.key0, a.key1);
             int32_t v = a.indices[live ? ra + (int64_t)__umulhi(rr, deg) : 0];
             if (!live) v = -1;
             hop1[t] = v;
@@ -246,8 +260,8 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
                 const int t = base + c * 64 + lane;
                 const uint32_t deg = (uint32_t)(cb[c] - ca[c]);
                 uint32_t rr = 0;
-                if (tape) { if (t < total) rr = tape[n0 + t]; }
-                else rr = gs::philox4x32_10_x(wlo, whi, 1u, (uint32_t)t, a.key0, a.key1);
+                if (tape) { if (t < total) rr = tape1[t]; }
+                else rr = gs::philox4x32_10_x(wlo, whi, hop_base + 1u, slot1 + (uint32_t)t, a.key0, a.key1);
                 const bool live = p[c] >= 0 && deg != 0;
                 if (p[c] >= 0 && deg == 0) atomicMax(&a.err[0], p[c] + 1);
                 v[c] = a.indices[live ? ca[c] + (int64_t)__umulhi(rr, deg) : 0];
@@ -470,8 +484,11 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         for (int ct = 0; ct < NT2; ++ct) {
             o[0][ct] = acc_s[ct][0] + b1_T[ct * 16 + r];
             o[1][ct] = acc_n[ct][0] + b1_T[HH2 + ct * 16 + r];
+            if (a.top_relu) { o[0][ct] = fmaxf(o[0][ct], 0.f); o[1][ct] = fmaxf(o[1][ct], 0.f); }
             ss += o[0][ct] * o[0][ct] + o[1][ct] * o[1][ct];
         }
+        if (a.out_h0 && lane < H1V)                  // the root's layer-0 output (the layer above reads it as a neighbor's)
+            *reinterpret_cast<float4 *>(a.out_h0 + (size_t)w * H1 + 4 * lane) = *reinterpret_cast<const float4 *>(H1t + 4 * lane);
         if (SAVE && q == 0) {
             float *dz = a.sv_z[side] + (size_t)pair * H2;
 #pragma unroll
@@ -523,10 +540,12 @@ void sage2_kernel(const Sage2Args a) {
     const int n_waves = blockDim.x >> 6;
     const long long my_blocks = (gridDim.x + 1 - side) >> 1;       // blocks serving this side
     const long long stride = my_blocks * n_waves;
-    const long long base = side ? a.n_pairs : 0;
+    // whole walks: the user roots first; subtrees: the item-typed roots first
+    const long long base = (a.sub_n ? !side : side) ? a.n_pairs : 0;
     auto load_root = [&](long long p) -> int32_t {                 // -1 for ids outside the graph
         const int32_t v = a.seeds[base + p];
-        return (unsigned long long)(long long)v < (unsigned long long)a.n_nodes ? v : -1;
+        if ((unsigned long long)(long long)v < (unsigned long long)a.n_nodes) return v;
+        return a.sub_n && v != -1 ? -2 : -1;
     };
     long long p = (long long)(blockIdx.x >> 1) * n_waves + wave;
     const bool has_work = p < a.n_pairs;
@@ -556,10 +575,10 @@ void sage2_kernel(const Sage2Args a) {
         const int32_t next_root = pn < a.n_pairs ? load_root(pn) : -1;
         int64_t nra = 0, nrb = 0;
         if (side == 0)
-            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF, SAVE>(a, p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF, SAVE>(a, base + p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_u, w0n_u, w0s_i, w0n_i, w1s, w1n, bias, bias + H1, bias + 2 * H1);
         else
-            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF, SAVE>(a, a.n_pairs + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF, SAVE>(a, base + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_i, w0n_i, w0s_u, w0n_u, w1s, w1n, bias + H1, bias, bias + 2 * H1);
         root = next_root; ra = nra; rb = nrb;
     }
@@ -621,17 +640,20 @@ extern "C" int gs_sage2_supported(int Fu, int Fi, int H1, int H2, int n0, int n1
     return found && sage2_lds(Fu, Fi, H1, H2, n0, n1) <= kLdsMax;
 }
 
-extern "C" int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
-                                const float *feat_user, int64_t n_users, int Fu,
-                                const float *feat_item, int64_t n_items, int Fi,
-                                const int32_t *seeds, int64_t n_pairs, int n0, int n1,
-                                uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
-                                const uint32_t *replay,
-                                const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
-                                const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
-                                int H1, int H2, int normalize,
-                                float *emb, int32_t *out_hop1, int32_t *out_hop2,
-                                const gs_sage2_saved *saved, int32_t *err_flag, void *stream) {
+namespace {
+
+int sage2_forward_impl(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
+                       const float *feat_user, int64_t n_users, int Fu,
+                       const float *feat_item, int64_t n_items, int Fi,
+                       const int32_t *seeds, int64_t n_pairs, int n0, int n1,
+                       uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
+                       const uint32_t *replay,
+                       const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                       const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                       int H1, int H2, int normalize,
+                       float *emb, int32_t *out_hop1, int32_t *out_hop2,
+                       const gs_sage2_saved *saved, const gs_sage2_subtrees *sub, int32_t *err_flag, void *stream) {
+
     if (n_pairs < 0) return gs::fail(GS_EINVAL, "gs_sage2_forward: n_pairs=%lld", (long long)n_pairs);
     if (n_pairs == 0) return GS_OK;
     if (!indptr || !indices || !feat_user || !feat_item || !seeds || !emb || !err_flag ||
@@ -652,13 +674,29 @@ extern "C" int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, i
     a.indptr = indptr; a.indices = indices; a.n_nodes = n_nodes;
     a.feat[0] = feat_user; a.feat[1] = feat_item; a.n_rows[0] = n_users; a.n_rows[1] = n_items;
     a.seeds = seeds; a.n_pairs = n_pairs; a.n0 = n0; a.n1 = n1;
+    a.tape_len = n0 + (long long)n0 * n1; a.tape_off0 = 0; a.tape_off1 = n0;
+    if (sub) {
+        if (saved) return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: no saved-activation form");
+        if (sub->roots_per_walk < 1 || n_pairs > ((int64_t)1 << 40) / sub->roots_per_walk)
+            return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: roots_per_walk=%d", sub->roots_per_walk);
+        if (replay && (sub->tape_len < 1 || sub->tape_off_hop2 < 0 || sub->tape_off_hop3 < 0 ||
+                       sub->tape_off_hop2 + (int64_t)sub->roots_per_walk * n0 > sub->tape_len ||
+                       sub->tape_off_hop3 + (int64_t)sub->roots_per_walk * n0 * n1 > sub->tape_len))
+            return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: the hops do not fit a tape of %lld words per walk", (long long)sub->tape_len);
+        if (sub->out_h0 && !aligned16(sub->out_h0)) return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: out_h0 must be 16-byte aligned");
+        a.sub_n = sub->roots_per_walk;
+        a.n_pairs = n_pairs * sub->roots_per_walk;           // roots per node type
+        a.top_relu = 1;
+        a.tape_len = sub->tape_len; a.tape_off0 = sub->tape_off_hop2; a.tape_off1 = sub->tape_off_hop3;
+        a.out_h0 = sub->out_h0;
+    }
     a.key0 = (unsigned)rng_seed; a.key1 = (unsigned)(rng_seed >> 32); a.walk_base = walk_id_base;
     a.walk_ids = walk_ids; a.replay = replay;
     a.w0_self[0] = l0_user->w_self; a.w0_neigh[0] = l0_user->w_neigh; a.b0[0] = l0_user->bias;
     a.w0_self[1] = l0_item->w_self; a.w0_neigh[1] = l0_item->w_neigh; a.b0[1] = l0_item->bias;
     a.w1_self[0] = l1_user->w_self; a.w1_neigh[0] = l1_user->w_neigh; a.b1[0] = l1_user->bias;
     a.w1_self[1] = l1_item->w_self; a.w1_neigh[1] = l1_item->w_neigh; a.b1[1] = l1_item->bias;
-    a.normalize = normalize; a.emb = emb; a.out_hop1 = out_hop1; a.out_hop2 = out_hop2; a.err = err_flag;
+    a.normalize = sub ? 0 : normalize; a.emb = emb; a.out_hop1 = out_hop1; a.out_hop2 = out_hop2; a.err = err_flag;
     a.ids_per_wave = ((n0 + n0 * n1) + 3) & ~3;
     a.h1_rows = 1 + n0;
     if (saved) {
@@ -682,4 +720,39 @@ extern "C" int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, i
     GS_SAGE2_CASES(GS_X)
 #undef GS_X
     return gs::fail(GS_ELIMIT, "gs_sage2_forward: no instantiation for Fu=%d Fi=%d H1=%d H2=%d", Fu, Fi, H1, H2);
+}
+
+}  // namespace
+
+extern "C" int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
+                                const float *feat_user, int64_t n_users, int Fu,
+                                const float *feat_item, int64_t n_items, int Fi,
+                                const int32_t *seeds, int64_t n_pairs, int n0, int n1,
+                                uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
+                                const uint32_t *replay,
+                                const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                                const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                                int H1, int H2, int normalize,
+                                float *emb, int32_t *out_hop1, int32_t *out_hop2,
+                                const gs_sage2_saved *saved, int32_t *err_flag, void *stream) {
+    return sage2_forward_impl(indptr, indices, n_nodes, feat_user, n_users, Fu, feat_item, n_items, Fi, seeds, n_pairs, n0, n1,
+                              rng_seed, walk_id_base, walk_ids, replay, l0_user, l0_item, l1_user, l1_item, H1, H2, normalize,
+                              emb, out_hop1, out_hop2, saved, nullptr, err_flag, stream);
+}
+
+extern "C" int gs_sage2_forward_subtrees(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
+                                         const float *feat_user, int64_t n_users, int Fu,
+                                         const float *feat_item, int64_t n_items, int Fi,
+                                         const int32_t *hop1_ids, int64_t n_pairs, int n1, int n2,
+                                         uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
+                                         const uint32_t *replay,
+                                         const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                                         const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                                         int H1, int H2,
+                                         float *h1_out, int32_t *out_hop2, int32_t *out_hop3,
+                                         const gs_sage2_subtrees *sub, int32_t *err_flag, void *stream) {
+    if (!sub) return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: null pointer argument");
+    return sage2_forward_impl(indptr, indices, n_nodes, feat_user, n_users, Fu, feat_item, n_items, Fi, hop1_ids, n_pairs, n1, n2,
+                              rng_seed, walk_id_base, walk_ids, replay, l0_user, l0_item, l1_user, l1_item, H1, H2, 0,
+                              h1_out, out_hop2, out_hop3, nullptr, sub, err_flag, stream);
 }

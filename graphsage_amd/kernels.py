@@ -714,9 +714,15 @@ class Sage2Call:
     """
 
     def __init__(self, indptr, indices, feat_user, feat_item, fanouts, weights, normalize, n_pairs,
-                 emb=None, keep_ids=False, saved=None):
+                 emb=None, keep_ids=False, saved=None, subtrees=None, hop_buffers=None):
         """``saved`` (training): {'x_self', 'x_mean', 'h1', 'x_mean1', 'z'} -> {'user': tensor, 'item':
-        tensor}, the buffers the kernel fills for the backward pass (layout in include/gsage.h)."""
+        tensor}, the buffers the kernel fills for the backward pass (layout in include/gsage.h).
+
+        ``subtrees`` = {'roots_per_walk': R, 'tape_len', 'tape_off_hop2', 'tape_off_hop3', 'out_h0'
+        (tensor (2*n_pairs*R, H1) or None)}: ``gs_sage2_forward_subtrees`` -- the roots given to
+        ``run`` are the 2*n_pairs*R hop-1 nodes of a three-hop model's walks, ``fanouts`` those of
+        hops 2 and 3, ``emb`` (2*n_pairs*R, H2) receives relu(layer 1) at every root.
+        ``hop_buffers`` = (int32 tensor, int32 tensor): where the drawn ids go (instead of ``keep_ids``)."""
         lib = load()
         _dev(indptr, torch.int64, 'indptr', 1)
         _dev(indices, torch.int32, 'indices', 1)
@@ -753,12 +759,33 @@ class Sage2Call:
                                   (fu, fi, h1, h2, n0, n1))
         dev = indptr.device
         self.n_pairs = int(n_pairs)
-        self.emb = emb if emb is not None else torch.empty((2 * self.n_pairs, h2), dtype=torch.float32, device=dev)
+        self._sub = None
+        self.n_roots = 2 * self.n_pairs
+        if subtrees is not None:
+            if saved is not None:
+                raise ValueError("the subtree form has no saved-activation variant")
+            r = int(subtrees['roots_per_walk'])
+            self.n_roots = 2 * self.n_pairs * r
+            out_h0 = subtrees.get('out_h0')
+            if out_h0 is not None:
+                _dev(out_h0, torch.float32, 'out_h0', 2)
+                if tuple(out_h0.shape) != (self.n_roots, h1):
+                    raise ValueError("out_h0 must be (%d, %d)" % (self.n_roots, h1))
+            self._sub = _lib.Sage2Subtrees(r, int(subtrees.get('tape_len', 0)), int(subtrees.get('tape_off_hop2', 0)),
+                                           int(subtrees.get('tape_off_hop3', 0)), ptr(out_h0))
+            self._sub_keep = out_h0
+        self.emb = emb if emb is not None else torch.empty((self.n_roots, h2), dtype=torch.float32, device=dev)
         _dev(self.emb, torch.float32, 'emb', 2)
-        if tuple(self.emb.shape) != (2 * self.n_pairs, h2):
-            raise ValueError("emb must be (%d, %d)" % (2 * self.n_pairs, h2))
-        self.hop1 = torch.empty((2 * self.n_pairs, n0), dtype=torch.int32, device=dev) if keep_ids else None
-        self.hop2 = torch.empty((2 * self.n_pairs, n0 * n1), dtype=torch.int32, device=dev) if keep_ids else None
+        if tuple(self.emb.shape) != (self.n_roots, h2):
+            raise ValueError("emb must be (%d, %d)" % (self.n_roots, h2))
+        self.hop1 = torch.empty((self.n_roots, n0), dtype=torch.int32, device=dev) if keep_ids else None
+        self.hop2 = torch.empty((self.n_roots, n0 * n1), dtype=torch.int32, device=dev) if keep_ids else None
+        if hop_buffers is not None:
+            self.hop1, self.hop2 = hop_buffers
+            for name, buf, n in (('hop_buffers[0]', self.hop1, self.n_roots * n0), ('hop_buffers[1]', self.hop2, self.n_roots * n0 * n1)):
+                _dev(buf, torch.int32, name)
+                if buf.numel() != n:
+                    raise ValueError("%s must have %d entries" % (name, n))
         self._saved = None
         if saved is not None:
             rows = self.n_pairs * (1 + n0)
@@ -813,16 +840,25 @@ class Sage2Call:
             self._read_weight_addresses()
         _dev(seeds, torch.int32, 'seeds', 1)
         _dev(err_flag, torch.int32, 'err_flag', 1)
-        if seeds.numel() != 2 * self.n_pairs:
-            raise ValueError("seeds must hold %d roots" % (2 * self.n_pairs))
+        if seeds.numel() != self.n_roots:
+            raise ValueError("seeds must hold %d roots" % self.n_roots)
         if walk_ids is not None:
             _dev(walk_ids, torch.int64, 'walk_ids', 1)
-            if walk_ids.numel() != seeds.numel():
-                raise ValueError("walk_ids must have one entry per seed")
+            if walk_ids.numel() != 2 * self.n_pairs:
+                raise ValueError("walk_ids must have one entry per seed walk")
         if replay is not None:
             _dev(replay, torch.int32, 'replay', 1)
-            if replay.numel() != seeds.numel() * self._tape_len:
+            words = 2 * self.n_pairs * (self._sub.tape_len if self._sub is not None else self._tape_len)
+            if replay.numel() != words:
                 raise ValueError("replay tape has the wrong length")
+        if self._sub is not None:
+            check(self._lib.gs_sage2_forward_subtrees(*self._fixed_a, ptr(seeds), self.n_pairs, self._n0, self._n1,
+                                                      int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(walk_id_base) & 0xFFFFFFFFFFFFFFFF,
+                                                      ptr(walk_ids), ptr(replay), *self._fixed_b[:6], ptr(self.emb),
+                                                      ptr(self.hop1), ptr(self.hop2), ctypes.byref(self._sub),
+                                                      ptr(err_flag), stream_handle()),
+                  'gs_sage2_forward_subtrees')
+            return self.emb
         check(self._lib.gs_sage2_forward(*self._fixed_a, ptr(seeds), self.n_pairs, self._n0, self._n1,
                                          int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(walk_id_base) & 0xFFFFFFFFFFFFFFFF,
                                          ptr(walk_ids), ptr(replay), *self._fixed_b,

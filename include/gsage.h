@@ -441,6 +441,47 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
                      const gs_sage2_saved *saved, int32_t *err_flag, void *stream);
 
 /*
+ * The same kernel below the first hop of a THREE-hop model (models.py:127-190 with three layers;
+ * sampler.py:65-90 to depth 3): every hop-1 node v of every walk is the root of a two-hop subtree -- v, its
+ * n1 sampled neighbors, their n2 sampled neighbors each -- and everything layer 1 of v depends on is
+ * private to that subtree.  One wavefront per subtree draws hops 2 and 3, gathers the subtree's
+ * 1 + n1 + n1*n2 feature rows, and leaves
+ *   h1_out[i, :]  = relu(layer 1 at v)     the row layer 2 reads as a neighbor's          [roots, H2]
+ *   out_h0[i, :]  = relu(layer 0 at v)     the row layer 1 of the walk's root reads       [roots, H1]
+ * so that neither the ids of hops 2 and 3 nor the layer-0 outputs of the hop-2 nodes pass through memory,
+ * and the sampler's pass over those hops (most of a walk's draws) is hidden behind the gathers.
+ *   hop1_ids   [2*n_pairs * roots_per_walk] the hop-1 nodes as gs_sample writes them (fanouts[0] =
+ *              roots_per_walk): those of the user-rooted walks (items) first; root i belongs to seed walk
+ *              i / roots_per_walk.  An id of -1 (below an isolated root) gives rows of zeros' images.
+ *   walk_ids   per SEED walk [2*n_pairs] (or NULL: walk_id_base + seed walk), rng_seed, replay: as gs_sample;
+ *              the draws are exactly those of gs_sample over three hops (counter hop = 1 and 2, slot =
+ *              the node's slot in the walk); the tape holds tape_len words per seed walk, hop 2 from word
+ *              tape_off_hop2 on, hop 3 from tape_off_hop3 on
+ *   n1, n2     fan-outs of hops 2 and 3;  l0_* / l1_*: the weights of layers 0 and 1
+ *   out_hop2 / out_hop3 (nullable) receive the drawn ids in gs_sample's layout
+ * What remains for the caller are the seed roots themselves: layer 0 and layer 1 at the roots (neighbors: the
+ * hop-1 nodes' feature rows / out_h0 rows) and layer 2 (neighbors: h1_out rows), e.g. through gs_sage_fused_fwd.
+ * Shapes: gs_sage2_supported(Fu, Fi, H1, H2, n1, n2).
+ */
+typedef struct gs_sage2_subtrees {
+    int32_t roots_per_walk;
+    int64_t tape_len, tape_off_hop2, tape_off_hop3;
+    float *out_h0;
+} gs_sage2_subtrees;
+
+int gs_sage2_forward_subtrees(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
+                              const float *feat_user, int64_t n_users, int Fu,
+                              const float *feat_item, int64_t n_items, int Fi,
+                              const int32_t *hop1_ids, int64_t n_pairs, int n1, int n2,
+                              uint64_t rng_seed, uint64_t walk_id_base, const int64_t *walk_ids,
+                              const uint32_t *replay,
+                              const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                              const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                              int H1, int H2,
+                              float *h1_out, int32_t *out_hop2, int32_t *out_hop3,
+                              const gs_sage2_subtrees *sub, int32_t *err_flag, void *stream);
+
+/*
  * The layer-0 relu masks for gs_sage2_backward_tail / gs_sage2_backward_tail_head (their nullable l0_mask argument), in which case g_h1 leaves as the
  * gradient at the layer-0 PRE-activations (g_h1 * [h1 > 0]) and the layer-0 weight gradients take it with
  * act = linear, without reading the forward output again:

@@ -235,6 +235,22 @@ int main() {
     sv.x_mean[1] = f; sv.h1_mask[0] = reinterpret_cast<uint32_t *>(i32);          // mask words for one node type only
     REFUSED(GS_EINVAL, gs_sage2_forward(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 25, 10, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, 1, f, nullptr, nullptr, &sv, i32, nullptr));
 
+    // ---- the same kernel below the first hop of a three-hop model ----
+    {
+        gs_sage2_subtrees sub{};
+        sub.roots_per_walk = 25; sub.tape_len = 25 + 250 + 1250; sub.tape_off_hop2 = 25; sub.tape_off_hop3 = 275;
+        ACCEPTED(gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 0, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, nullptr, i32, nullptr));
+        REFUSED(GS_ELIMIT, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 24, f, 40, 19, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        sub.tape_off_hop3 = sub.tape_len - 10;                  // hop 3 runs past the end of a walk's tape
+        REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr,
+                                                     reinterpret_cast<const uint32_t *>(i32), &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        sub.tape_off_hop3 = 275; sub.roots_per_walk = 0;
+        REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        sub.roots_per_walk = 25; sub.out_h0 = odd;
+        REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+    }
+
     // ---- top of the backward pass ----
     ACCEPTED(gs_sage2_backward_tail(f, f, f, f, 0, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));
     REFUSED(GS_EINVAL, gs_sage2_backward_tail(f, f, f, f, -1, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));

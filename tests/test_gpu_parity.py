@@ -618,6 +618,49 @@ def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_
         start += nh
 
 
+@pytest.mark.parametrize('ns,sizes,fu,fi,b', [([6, 4, 3], [32, 32, 32], 64, 64, 24), ([25, 10, 5], [32, 32, 32], 64, 64, 40),
+                                                ([3, 5, 2], [64, 64, 32], 64, 64, 130), ([4, 3, 2], [32, 32, 64], 32, 32, 7)])
+def test_three_hop_engine_through_the_subtree_kernel(cuda, ns, sizes, fu, fi, b):
+    """Three hops with everything below the first hop in one kernel (gs_sage2_forward_subtrees): the ids it
+    draws are gs_sample's, with Philox keys and with a replay tape, and the embeddings equal those of the
+    layer-by-layer kernels."""
+    from graphsage_amd.engine import SageForwardEngine
+    rng = np.random.default_rng(b)
+    nu, ni = 400, 90
+    u = np.concatenate([rng.integers(0, nu, 3000), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 3000), np.arange(nu) % ni]) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, fu)).astype(np.float32),
+             'item': rng.standard_normal((ni, fi)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=4)
+    model = ga.GraphSAGE(sizes, gen, seed=6).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.1, 0.1)
+    seeds = torch.tensor(list(e[0, :b]) + list(e[1, :b]), dtype=torch.int32, device=cuda)
+    walk_ids = torch.arange(100, 100 + 2 * b, dtype=torch.int64, device=cuda)
+    eng_s = SageForwardEngine(g, model, b, keep_ids=True, subtree_kernel=True)
+    eng_g = SageForwardEngine(g, model, b)                             # sampler + one fused kernel per layer and type
+    assert eng_s.subtree_kernel and not eng_g.subtree_kernel
+    tape = torch.from_numpy(rng.integers(0, 2 ** 32, 2 * b * sum(eng_s.sizes[1:]), dtype=np.uint64).astype(np.uint32)
+                            .view(np.int32)).to(cuda)
+    for kw in ({'rng_seed': 77}, {'rng_seed': 0, 'replay': tape}):
+        out_s = [x.clone() for x in eng_s.forward(seeds, walk_ids, **kw)]
+        out_g = [x.clone() for x in eng_g.forward(seeds, walk_ids, **kw)]
+        assert eng_s.err_flag.tolist() == [0, 0]
+        for a, c in zip(eng_s.hops, eng_g.hops):
+            assert torch.equal(a, c)
+        for a, c in zip(out_s, out_g):
+            close(a, c.double(), scale=float(c.abs().max()))
+    # the ids also against the CPU walker
+    want = walker.walk_vectorised(g.indptr, g.indices, seeds.cpu().numpy(), ns, rng_seed=77, first_walk=100)
+    eng_s.forward(seeds, walk_ids, rng_seed=77)
+    for a, c in zip(eng_s.hops, want):
+        np.testing.assert_array_equal(a.cpu().numpy().astype(np.int64), c)
+
+
 def test_engine_wide_kernel_on_every_layer_matches_general_kernels(cuda):
     """A wide three-hop model with the row threshold lowered so that every layer -- dense activation
     rows from layer 1 on -- goes through the wide kernel: same embeddings as the general kernels."""
