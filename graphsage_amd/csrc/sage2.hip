@@ -65,7 +65,7 @@ struct Sage2Args {
     // Subtree mode (sub_n > 0): root i is hop-1 node i % sub_n of seed walk i / sub_n of a deeper model, whose
     // hops 1 and 2 this kernel draws (sampler hop = local hop + 1, slots shifted by the subtree's position);
     // the item-typed roots come first (they hang below the user-rooted seed walks).
-    int sub_n, top_relu;
+    int sub_n;
     long long tape_len, tape_off0, tape_off1;         // replay tape: words per seed walk, offsets of local hops 0 / 1
     float *out_h0;                                    // nullable: [roots, H1] layer-0 output of every root
 };
@@ -192,7 +192,7 @@ struct Sage2Shape {
 };
 
 // One walk.  FT / FO: feature widths of the root's type and of the other type.
-template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, bool SAVE>
+template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, bool SAVE, bool SUB>
 __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int side, int lane,
                                           int32_t root, int64_t ra, int64_t rb,
                                           int32_t next_root, int64_t &next_ra, int64_t &next_rb,
@@ -215,16 +215,17 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     // ---- sampling ---------------------------------------------------------------
     // the caller maps out-of-range roots to -1, or to -2 where -1 itself is a legitimate entry (subtree roots
     // below an isolated node, which the sampler has reported)
-    if (root < (a.sub_n ? -1 : 0) && lane == 0) atomicMax(&a.err[1], 1);
+    if (root < (SUB ? -1 : 0) && lane == 0) atomicMax(&a.err[1], 1);
     // seed walk and position below it (whole walks: the walk itself, position 0)
-    const long long seed_walk = a.sub_n ? w / a.sub_n : w;
-    const unsigned sub_j = a.sub_n ? (unsigned)(w - seed_walk * a.sub_n) : 0u;
-    const unsigned hop_base = a.sub_n ? 1u : 0u;
+    const long long seed_walk = SUB ? w / a.sub_n : w;
+    const unsigned sub_j = SUB ? (unsigned)(w - seed_walk * a.sub_n) : 0u;
+    constexpr unsigned hop_base = SUB ? 1u : 0u;
     const unsigned slot0 = sub_j * (unsigned)n0, slot1 = sub_j * (unsigned)(n0 * n1);
     const unsigned long long walk = a.walk_ids ? (unsigned long long)a.walk_ids[seed_walk] : a.walk_base + (unsigned long long)seed_walk;
     const unsigned wlo = (unsigned)walk, whi = (unsigned)(walk >> 32);
-    const uint32_t *tape = a.replay ? a.replay + (size_t)seed_walk * a.tape_len : nullptr;
-    const uint32_t *tape0 = tape ? tape + a.tape_off0 + slot0 : nullptr, *tape1 = tape ? tape + a.tape_off1 + slot1 : nullptr;
+    const uint32_t *tape = a.replay ? a.replay + (size_t)seed_walk * (SUB ? a.tape_len : (long long)(n0 + n0 * n1)) : nullptr;
+    const uint32_t *tape0 = tape ? tape + (SUB ? a.tape_off0 + slot0 : 0) : nullptr;
+    const uint32_t *tape1 = tape ? tape + (SUB ? a.tape_off1 + slot1 : (long long)n0) : nullptr;
     wave_lds_fence();                        // the previous walk's readers of s_ids / A / H1t are done
     {
         const uint32_t deg = (uint32_t)(rb - ra);
@@ -484,17 +485,17 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         for (int ct = 0; ct < NT2; ++ct) {
             o[0][ct] = acc_s[ct][0] + b1_T[ct * 16 + r];
             o[1][ct] = acc_n[ct][0] + b1_T[HH2 + ct * 16 + r];
-            if (a.top_relu) { o[0][ct] = fmaxf(o[0][ct], 0.f); o[1][ct] = fmaxf(o[1][ct], 0.f); }
+            if (SUB) { o[0][ct] = fmaxf(o[0][ct], 0.f); o[1][ct] = fmaxf(o[1][ct], 0.f); }   // an inner layer
             ss += o[0][ct] * o[0][ct] + o[1][ct] * o[1][ct];
         }
-        if (a.out_h0 && lane < H1V)                  // the root's layer-0 output (the layer above reads it as a neighbor's)
+        if (SUB && a.out_h0 && lane < H1V)           // the root's layer-0 output (the layer above reads it as a neighbor's)
             *reinterpret_cast<float4 *>(a.out_h0 + (size_t)w * H1 + 4 * lane) = *reinterpret_cast<const float4 *>(H1t + 4 * lane);
         if (SAVE && q == 0) {
             float *dz = a.sv_z[side] + (size_t)pair * H2;
 #pragma unroll
             for (int ct = 0; ct < NT2; ++ct) { dz[ct * 16 + r] = o[0][ct]; dz[HH2 + ct * 16 + r] = o[1][ct]; }
         }
-        if (a.normalize) {
+        if (!SUB && a.normalize) {
 #pragma unroll
             for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m, 64);
             const float inv = rsqrtf(fmaxf(ss, 1e-12f));
@@ -512,7 +513,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     }
 }
 
-template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE>
+template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB>
 __global__ __launch_bounds__(max_waves(HH1) * 64)
 void sage2_kernel(const Sage2Args a) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
@@ -541,11 +542,11 @@ void sage2_kernel(const Sage2Args a) {
     const long long my_blocks = (gridDim.x + 1 - side) >> 1;       // blocks serving this side
     const long long stride = my_blocks * n_waves;
     // whole walks: the user roots first; subtrees: the item-typed roots first
-    const long long base = (a.sub_n ? !side : side) ? a.n_pairs : 0;
+    const long long base = (SUB ? !side : side) ? a.n_pairs : 0;
     auto load_root = [&](long long p) -> int32_t {                 // -1 for ids outside the graph
         const int32_t v = a.seeds[base + p];
         if ((unsigned long long)(long long)v < (unsigned long long)a.n_nodes) return v;
-        return a.sub_n && v != -1 ? -2 : -1;
+        return SUB && v != -1 ? -2 : -1;
     };
     long long p = (long long)(blockIdx.x >> 1) * n_waves + wave;
     const bool has_work = p < a.n_pairs;
@@ -575,23 +576,23 @@ void sage2_kernel(const Sage2Args a) {
         const int32_t next_root = pn < a.n_pairs ? load_root(pn) : -1;
         int64_t nra = 0, nrb = 0;
         if (side == 0)
-            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF, SAVE>(a, base + p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF, SAVE, SUB>(a, base + p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_u, w0n_u, w0s_i, w0n_i, w1s, w1n, bias, bias + H1, bias + 2 * H1);
         else
-            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF, SAVE>(a, base + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF, SAVE, SUB>(a, base + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_i, w0n_i, w0s_u, w0n_u, w1s, w1n, bias + H1, bias, bias + 2 * H1);
         root = next_root; ra = nra; rb = nrb;
     }
 }
 
-template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE>
+template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB = false>
 int launch_one(const Sage2Args &a, hipStream_t stream) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     int waves = max_waves(HH1);                          // as many waves per CU as the LDS budget admits
     while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves) > kLdsMax) waves -= 2;
     const size_t lds = S::lds_bytes(a.n0, a.n1, waves);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
-    auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF, SAVE>;
+    auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF, SAVE, SUB>;
     static thread_local const void *configured = nullptr;
     if (lds > 64 * 1024 && configured != (const void *)kern) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
@@ -609,6 +610,7 @@ int launch(const Sage2Args &a, hipStream_t stream) {
     // buffer addressing needs both tables inside a 4 GiB window
     const long long lim = 0xFFFFF000LL;                  // RowTable::kNoRow must lie past the end of both tables
     const bool buf = a.n_rows[0] * FU * 4 < lim && a.n_rows[1] * FI * 4 < lim;
+    if (a.sub_n) return buf ? launch_one<FU, FI, HH1, HH2, true, false, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, false, true>(a, stream);
     if (a.sv_z[0]) return buf ? launch_one<FU, FI, HH1, HH2, true, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, true>(a, stream);
     return buf ? launch_one<FU, FI, HH1, HH2, true, false>(a, stream) : launch_one<FU, FI, HH1, HH2, false, false>(a, stream);
 }
@@ -686,7 +688,6 @@ int sage2_forward_impl(const int64_t *indptr, const int32_t *indices, int64_t n_
         if (sub->out_h0 && !aligned16(sub->out_h0)) return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: out_h0 must be 16-byte aligned");
         a.sub_n = sub->roots_per_walk;
         a.n_pairs = n_pairs * sub->roots_per_walk;           // roots per node type
-        a.top_relu = 1;
         a.tape_len = sub->tape_len; a.tape_off0 = sub->tape_off_hop2; a.tape_off1 = sub->tape_off_hop3;
         a.out_h0 = sub->out_h0;
     }
