@@ -15,7 +15,8 @@ from this script itself: ``python bench.py --gpus N`` starts N ranks and relays 
 
 Environment switches for comparisons: BENCH_UNFUSED=1 runs the forward pass on the
 general kernels (sample, gather-mean, projection) instead of the fused ones;
-BENCH_SUBTREE_KERNEL=1 runs three-hop workloads through the one-wavefront-per-subtree kernel;
+BENCH_LAYERED=1 runs narrow three-hop workloads through the sampler + one kernel per layer and
+node type instead of the two-launch route;
 BENCH_DRAW_IN_LAYER=1 lets the layer-0 kernel of the layered routes draw the deepest hop
 itself (the sampler kernel then stops one hop short);
 BENCH_EAGER_TRAIN=1 launches the training step kernel by kernel instead of
@@ -50,7 +51,7 @@ WORKLOADS = {
                     desc="cfg2 with 64 hidden units per layer instead of the reference's 32"),
     'cfg2h3': dict(nu=1_000_000, ni=100_000, e=50_000_000, fu=64, fi=64, fan=[25, 10, 5], layers=[32, 32, 32],
                    alpha_item=1.1, alpha_user=None,
-                   desc="cfg2 graph and widths, 3-hop [25,10,5] (layered path: sampler + one fused kernel per layer and type)"),
+                   desc="cfg2 graph and widths, 3-hop [25,10,5] (two launches: everything below the seeds, then the seeds' layers)"),
     'ml1m': dict(nu=6040, ni=3706, e=226_310, fu=24, fi=19, fan=[10, 5], layers=[32, 32],
                  alpha_item=0.9, alpha_user=None,
                  desc="MovieLens-1M-shaped synthetic 6040 x 3706, 226k edges, 2-hop [10,5]"),
@@ -341,7 +342,7 @@ def main():
     model = ga.GraphSAGE(cfg['layers'], gen, seed=7).build()
     engine = SageForwardEngine(graph, model, b, use_fused=not os.environ.get('BENCH_UNFUSED'),
                                draw_in_layer=bool(os.environ.get('BENCH_DRAW_IN_LAYER')),
-                               subtree_kernel=bool(os.environ.get('BENCH_SUBTREE_KERNEL')))
+                               subtree_kernel=not os.environ.get('BENCH_LAYERED'))
     engine.static_weights = True         # inference: padded weight copies (odd feature widths) are made once
 
     # per-step inputs, resident in HBM: roots (sources then destinations) and the walk ids

@@ -103,7 +103,7 @@ class Sage2Saved(_c.Structure):
 class Sage2Subtrees(_c.Structure):
     """gs_sage2_subtrees of include/gsage.h."""
     _fields_ = [('roots_per_walk', _i32), ('tape_len', _i64), ('tape_off_hop2', _i64), ('tape_off_hop3', _i64),
-                ('out_h0', _vp)]
+                ('out_h0', _vp), ('seeds', _vp), ('out_hop1', _vp)]
 
 
 class Sage2L0Mask(_c.Structure):
@@ -122,6 +122,9 @@ SIGNATURES['gs_sage2_forward_subtrees'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i3
                                                   _c.POINTER(SageWeights), _c.POINTER(SageWeights),
                                                   _c.POINTER(SageWeights), _c.POINTER(SageWeights),
                                                   _i32, _i32, _vp, _vp, _vp, _c.POINTER(Sage2Subtrees), _vp, _vp])
+SIGNATURES['gs_sage3_seeds_supported'] = (_i32, [_i32] * 6)
+SIGNATURES['gs_sage3_seeds_forward'] = (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp, _vp] +
+                                        [_c.POINTER(SageWeights)] * 6 + [_i32, _i32, _i32, _i32, _i32, _vp, _vp])
 SIGNATURES['gs_sage2_backward_tail'] = (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
                                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(Sage2L0Mask), _vp])
 

@@ -42,6 +42,7 @@ constexpr int heads_in_flight(int hh1) { return hh1 >= 32 ? 2 : 1; }
 constexpr int kUnroll = 10;              // row loads in flight per lane in the mean phase
 constexpr int kChunks = 4;               // 64-slot chunks sampled per pass
 constexpr size_t kLdsMax = 160 * 1024;
+constexpr int kGroup = 8;                // subtree mode: roots a wavefront takes together
 
 struct Sage2Args {
     const int64_t *indptr; const int32_t *indices; long long n_nodes;
@@ -68,6 +69,10 @@ struct Sage2Args {
     int sub_n;
     long long tape_len, tape_off0, tape_off1;         // replay tape: words per seed walk, offsets of local hops 0 / 1
     float *out_h0;                                    // nullable: [roots, H1] layer-0 output of every root
+    // nullable: the 2*n_pairs/sub_n seed nodes.  Then the roots themselves are drawn here (sampler hop 0 of the
+    // seed walks, slot = the root's position below its seed) and written to hop1_out instead of read from seeds.
+    const int32_t *seeds0;
+    int32_t *hop1_out;
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -184,9 +189,10 @@ struct Sage2Shape {
     static constexpr int W0_FLOATS = 2 * (FU + FI) * HH1;
     static constexpr int W1_FLOATS = 2 * H1 * HH2;          // a block serves one side: one layer-1 weight set
     static constexpr int B_FLOATS = 2 * H1 + H2;
-    static size_t lds_bytes(int n0, int n1, int waves) {
-        const int ids = ((n0 + n0 * n1) + 3) & ~3;
-        const int h1_rows = 1 + n0;
+    // roots: 0 for whole walks, kGroup in subtree mode
+    static size_t lds_bytes(int n0, int n1, int waves, int roots = 0) {
+        const int ids = ((roots ? roots : 1) * (n0 + n0 * n1) + 3) & ~3;
+        const int h1_rows = roots ? roots : 1 + n0;          // subtree mode keeps the roots' rows only
         return (size_t)(W0_FLOATS + W1_FLOATS + B_FLOATS + waves * (16 * LDA + h1_rows * LDH + ids)) * sizeof(float);
     }
 };
@@ -513,6 +519,320 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     }
 }
 
+// Subtree mode, G roots per wavefront.  A subtree of fan-outs [10, 5] is 61 rows behind the same chain of
+// dependent reads as a whole walk; taking G subtrees through that chain together -- their hop-1 heads as ONE
+// list of G * n0 heads, the G roots as G rows of one tile -- amortises it the way a walk of fan-outs [25, 10]
+// does.  Roots are consecutive entries of the hop-1 array (they may belong to different seed walks: walk id
+// and slot offsets are per root).  Same arithmetic as walk_body with SUB; the neighbor sum of a root is taken
+// over its heads in list order.
+template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, int G>
+__device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int n_valid, int side, int lane,
+                                           int32_t rootv, int64_t rav, int64_t rbv, unsigned long long walkv,
+                                           float *A, float *H1t, int32_t *s_ids,
+                                           const float *W0s_T, const float *W0n_T, const float *W0s_O, const float *W0n_O,
+                                           const float *W1s_T, const float *W1n_T,
+                                           const float *b0_T, const float *b0_O, const float *b1_T) {
+    constexpr bool SAVE = false;
+    constexpr int NT1 = HH1 / 16, NT2 = HH2 / 16, H1 = 2 * HH1, H2 = 2 * HH2;
+    constexpr int FTV = FT / 4, FOV = FO / 4, H1V = H1 / 4;
+    constexpr int RS_N = (G * FOV + 63) / 64, RT_N = (G * FTV + 63) / 64;
+    constexpr int L1_N = (G * H1V + 63) / 64;
+    static_assert(G >= 1 && G <= 16, "the roots are rows 0 .. G-1 of one 16-row tile");
+    const int r = lane & 15, q = lane >> 4;
+    const int n0 = a.n0, n1 = a.n1, NH = G * n0;
+    RowTable<BUF> tabT, tabO;
+    tabT.init(a.feat[side], a.n_rows[side], FT * 4);
+    tabO.init(a.feat[1 - side], a.n_rows[1 - side], FO * 4);
+    const int offT = side ? (int)a.n_rows[0] : 0, offO = side ? 0 : (int)a.n_rows[0];
+    int32_t *hop1 = s_ids, *hop2 = s_ids + NH;
+    int wl = lane;
+    asm volatile("" : "+v"(wl));            // keeps the weight-fragment reads inside the group loop
+    const long long sv_h1row = 0, pair = 0; // (names the shared tile loop mentions in its saving branches)
+    (void)sv_h1row; (void)pair;
+
+    // lane g < G carries root g: id (-1 / -2: none), CSR row bounds, walk id; position below its seed walk
+    const long long my_w = w0 + min(lane, n_valid - 1);          // (lanes past the valid roots repeat the last one)
+    const long long my_seed = my_w / a.sub_n;
+    const unsigned my_j = (unsigned)(my_w - my_seed * a.sub_n);
+    if (lane < n_valid && rootv < -1) atomicMax(&a.err[1], 1);
+    if (lane < n_valid && rootv >= 0 && rbv == rav) atomicMax(&a.err[0], rootv + 1);
+    // the roots' own rows: requested now, used after the heads' tiles
+    float4 own_root[RT_N];
+#pragma unroll
+    for (int k = 0; k < RT_N; ++k) {
+        const int idx = k * 64 + lane, g = min(idx / FTV, G - 1), c = idx % FTV;
+        const int32_t rg = __shfl(rootv, g, 64);
+        own_root[k] = tabT.load(idx < G * FTV && g < n_valid && rg >= 0, (unsigned)(rg - offT), (unsigned)c * 16u, FT * 4);
+    }
+
+    // ---- sampling ---------------------------------------------------------------
+    wave_lds_fence();                        // the previous group's readers of s_ids / A / H1t are done
+    for (int t0 = 0; t0 < NH; t0 += 64) {    // (whole-wave trips: the shuffles below read lanes 0 .. G-1)
+        const int t = min(t0 + lane, NH - 1);
+        const int g = t / n0, tl = t - g * n0;
+        const int32_t rg = __shfl(rootv, g, 64);
+        const int64_t ra = __shfl(rav, g, 64), rb = __shfl(rbv, g, 64);
+        const unsigned long long wk = __shfl(walkv, g, 64);
+        const long long sw = __shfl(my_seed, g, 64);
+        const unsigned slot = __shfl(my_j, g, 64) * (unsigned)n0 + (unsigned)tl;
+        const uint32_t deg = (uint32_t)(rb - ra);
+        const bool live = g < n_valid && rg >= 0 && deg != 0;
+        const uint32_t rr = a.replay ? a.replay[(size_t)sw * a.tape_len + a.tape_off0 + slot]
+                                     : gs::philox4x32_10_x((unsigned)wk, (unsigned)(wk >> 32), 1u, slot, a.key0, a.key1);
+        int32_t v = a.indices[live ? ra + (int64_t)__umulhi(rr, deg) : 0];
+        if (!live) v = -1;
+        if (t0 + lane < NH) {
+            hop1[t] = v;
+            if (a.out_hop1 && g < n_valid) a.out_hop1[(size_t)(w0 + g) * n0 + tl] = v;
+        }
+    }
+    wave_lds_fence();
+    {
+        const int total = NH * n1, per_root = n0 * n1;
+        for (int base = 0; base < total; base += kChunks * 64) {
+            int32_t p[kChunks];
+            int64_t ca[kChunks], cb[kChunks];
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int t = base + c * 64 + lane;
+                p[c] = t < total ? hop1[t / n1] : -1;
+                const int32_t pc = p[c] >= 0 ? p[c] : 0;
+                ca[c] = a.indptr[pc];
+                cb[c] = a.indptr[pc + 1];
+            }
+            int32_t v[kChunks];
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int t = min(base + c * 64 + lane, total - 1);
+                const int g = t / per_root, local = t - g * per_root;
+                const unsigned long long wk = __shfl(walkv, g, 64);
+                const long long sw = __shfl(my_seed, g, 64);
+                const unsigned slot = __shfl(my_j, g, 64) * (unsigned)per_root + (unsigned)local;
+                const uint32_t deg = (uint32_t)(cb[c] - ca[c]);
+                const uint32_t rr = a.replay ? a.replay[(size_t)sw * a.tape_len + a.tape_off1 + slot]
+                                             : gs::philox4x32_10_x((unsigned)wk, (unsigned)(wk >> 32), 2u, slot, a.key0, a.key1);
+                const bool live = p[c] >= 0 && deg != 0;
+                if (p[c] >= 0 && deg == 0) atomicMax(&a.err[0], p[c] + 1);
+                v[c] = a.indices[live ? ca[c] + (int64_t)__umulhi(rr, deg) : 0];
+                if (!live) v[c] = -1;
+            }
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int t = base + c * 64 + lane;
+                if (t < total) {
+                    const int g = t / per_root, local = t - g * per_root;
+                    hop2[t] = tabT.entry(v[c], offT, FT * 4);
+                    if (a.out_hop2 && g < n_valid) a.out_hop2[(size_t)(w0 + g) * per_root + local] = v[c];
+                }
+            }
+        }
+    }
+    wave_lds_fence();
+
+    // ---- layer 0, the heads (type O; children type T) ------------------------------------
+    float4 rs[RS_N];                         // lane (g, c): column chunk c of the sum of root g's heads' own rows
+    float4 hs[L1_N];                         // lane (g, c): the same of root g's heads' layer-0 outputs
+#pragma unroll
+    for (int k = 0; k < RS_N; ++k) rs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < L1_N; ++k) hs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int RP_O = 64 / FOV, NPASS_O = 16 / RP_O;     // own rows per load instruction / passes per tile
+    constexpr int GN_T = 64 / FTV;                           // lane groups summing children rows
+    const int rounds = (n1 + kUnroll - 1) / kUnroll;
+    const int per = (n1 + rounds - 1) / rounds;
+    for (int j0 = 0; j0 < NH; j0 += 16) {
+        const int np = min(16, NH - j0);
+        float4 own[NPASS_O];
+#pragma unroll
+        for (int pass = 0; pass < NPASS_O; ++pass) {
+            const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
+            const int32_t id = hop1[j0 + min(rr, np - 1)];
+            own[pass] = tabO.load(rr < np, (unsigned)(id - offO), (unsigned)c * 16u, FO * 4);
+        }
+        {
+            // kHeads heads per lane group and iteration: their row loads are all issued before
+            // the first add, which is what keeps enough bytes in flight per wave
+            const int g = lane / FTV, c = lane % FTV;
+            const unsigned col = (unsigned)c * 16u;
+            const float denom = (float)n1;
+            constexpr int kHeads = heads_in_flight(HH1);
+            for (int pp0 = g; pp0 < 16; pp0 += kHeads * GN_T) {
+                float4 acc[kHeads];
+#pragma unroll
+                for (int hd = 0; hd < kHeads; ++hd) acc[hd] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c0 = 0; c0 < n1; c0 += per) {
+                    float4 v[kHeads][kUnroll];
+#pragma unroll
+                    for (int hd = 0; hd < kHeads; ++hd) {
+                        const int pp = pp0 + hd * GN_T;
+                        const int32_t *ids = hop2 + (j0 + min(pp, np - 1)) * n1;
+                        int32_t cid[kUnroll];                 // all id reads first: one LDS wait per batch
+#pragma unroll
+                        for (int u = 0; u < kUnroll; ++u) cid[u] = ids[min(c0 + u, n1 - 1)];
+#pragma unroll
+                        for (int u = 0; u < kUnroll; ++u) {
+                            const bool want = (pp < np) && (u < per) && (c0 + u < n1);
+                            v[hd][u] = tabT.load_entry(want, cid[u], col, FT * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int hd = 0; hd < kHeads; ++hd)
+#pragma unroll
+                        for (int u = 0; u < kUnroll; ++u) {
+                            acc[hd].x += v[hd][u].x; acc[hd].y += v[hd][u].y;
+                            acc[hd].z += v[hd][u].z; acc[hd].w += v[hd][u].w;
+                        }
+                }
+#pragma unroll
+                for (int hd = 0; hd < kHeads; ++hd) {
+                    const int pp = pp0 + hd * GN_T;
+                    if (pp < 16) {
+                        const float4 mean = make_float4(acc[hd].x / denom, acc[hd].y / denom, acc[hd].z / denom, acc[hd].w / denom);
+                        *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) = mean;
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+        if (SAVE) {                          // the tile of neighbor means, out of LDS: np consecutive table rows
+            float *dst = a.sv_x_mean[1 - side] + (size_t)(sv_h1row + j0) * FT;
+            for (int i = lane; i < np * FTV; i += 64)
+                stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(A + (i / FTV) * LDA + 4 * (i % FTV)));
+        }
+        f32x4 acc_s[NT1], acc_n[NT1];
+#pragma unroll
+        for (int ct = 0; ct < NT1; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_tile<FT, NT1>(A, LDA, W0n_O, wl, r, q, acc_n);
+        wave_lds_fence();
+#pragma unroll
+        for (int pass = 0; pass < NPASS_O; ++pass) {
+            const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
+            *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = own[pass];
+            if (SAVE && a.sv_x_self[1 - side] && rr < np)
+                stream_store(a.sv_x_self[1 - side] + (size_t)(sv_h1row + j0 + rr) * FO + 4 * c, own[pass]);
+        }
+        wave_lds_fence();
+        mma_tile<FO, NT1>(A, LDA, W0s_O, wl, r, q, acc_s);
+        // the tile's own rows (still in A) summed per root: they are the roots' layer-0 neighbors
+#pragma unroll
+        for (int k = 0; k < RS_N; ++k) {
+            const int idx = k * 64 + lane, g = idx / FOV, c = idx % FOV;
+            if (idx < G * FOV) {
+                const int lo = max(j0, g * n0) - j0, hi = min(j0 + np, (g + 1) * n0) - j0;
+                for (int rr = lo; rr < hi; ++rr) {
+                    const float4 t = *reinterpret_cast<const float4 *>(A + rr * LDA + 4 * c);
+                    rs[k].x += t.x; rs[k].y += t.y; rs[k].z += t.z; rs[k].w += t.w;
+                }
+            }
+        }
+        wave_lds_fence();
+        // the tile's activations go through A (the operands are used up) into the per-root sums: layer 1 needs
+        // only the mean of a root's heads, so no head's row outlives its tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float *dst = A + (4 * q + i) * LDA;
+#pragma unroll
+            for (int ct = 0; ct < NT1; ++ct) {
+                dst[ct * 16 + r] = fmaxf(acc_s[ct][i] + b0_O[ct * 16 + r], 0.f);
+                dst[HH1 + ct * 16 + r] = fmaxf(acc_n[ct][i] + b0_O[HH1 + ct * 16 + r], 0.f);
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < L1_N; ++k) {
+            const int idx = k * 64 + lane, g = idx / H1V, c = idx % H1V;
+            if (idx < G * H1V) {
+                const int lo = max(j0, g * n0) - j0, hi = min(j0 + np, (g + 1) * n0) - j0;
+                for (int rr = lo; rr < hi; ++rr) {
+                    const float4 t = *reinterpret_cast<const float4 *>(A + rr * LDA + 4 * c);
+                    hs[k].x += t.x; hs[k].y += t.y; hs[k].z += t.z; hs[k].w += t.w;
+                }
+            }
+        }
+        wave_lds_fence();                    // A is rewritten by the next tile
+    }
+
+
+    // ---- layer 0, the roots (type T): rows 0 .. G-1 of one tile --------------------------------
+    {
+        const float d0 = (float)n0;
+#pragma unroll
+        for (int k = 0; k < RS_N; ++k) {
+            const int idx = k * 64 + lane;
+            if (idx < G * FOV)
+                *reinterpret_cast<float4 *>(A + (idx / FOV) * LDA + 4 * (idx % FOV)) =
+                    make_float4(rs[k].x / d0, rs[k].y / d0, rs[k].z / d0, rs[k].w / d0);
+        }
+        wave_lds_fence();
+        f32x4 acc_s[NT1], acc_n[NT1];
+#pragma unroll
+        for (int ct = 0; ct < NT1; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_tile<FO, NT1>(A, LDA, W0n_T, wl, r, q, acc_n);
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < RT_N; ++k) {
+            const int idx = k * 64 + lane;
+            if (idx < G * FTV) *reinterpret_cast<float4 *>(A + (idx / FTV) * LDA + 4 * (idx % FTV)) = own_root[k];
+        }
+        wave_lds_fence();
+        mma_tile<FT, NT1>(A, LDA, W0s_T, wl, r, q, acc_s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {        // row 4q + i of D lives in register i of lane quarter q
+            const int row = 4 * q + i;
+            if (row < G) {
+#pragma unroll
+                for (int ct = 0; ct < NT1; ++ct) {
+                    H1t[row * LDH + ct * 16 + r] = fmaxf(acc_s[ct][i] + b0_T[ct * 16 + r], 0.f);
+                    H1t[row * LDH + HH1 + ct * 16 + r] = fmaxf(acc_n[ct][i] + b0_T[HH1 + ct * 16 + r], 0.f);
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+
+    // ---- layer 1 at the roots, on the LDS-resident activations ----------------------------------
+    {
+        const float d0 = (float)n0;
+#pragma unroll
+        for (int k = 0; k < L1_N; ++k) {     // lane (g, c): column chunk c of the mean of root g's heads' activations
+            const int idx = k * 64 + lane;
+            if (idx < G * H1V) {
+                const int g = idx / H1V, c = idx % H1V;
+                *reinterpret_cast<float4 *>(A + g * LDA + 4 * c) = make_float4(hs[k].x / d0, hs[k].y / d0, hs[k].z / d0, hs[k].w / d0);
+                if (a.out_h0 && g < n_valid)     // the root's layer-0 output (the layer above reads it as a neighbor's)
+                    *reinterpret_cast<float4 *>(a.out_h0 + (size_t)(w0 + g) * H1 + 4 * c) = *reinterpret_cast<const float4 *>(H1t + g * LDH + 4 * c);
+            }
+        }
+        wave_lds_fence();
+        f32x4 acc_s[NT2], acc_n[NT2];
+#pragma unroll
+        for (int ct = 0; ct < NT2; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_tile<H1, NT2>(A, LDA, W1n_T, wl, r, q, acc_n);
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < L1_N; ++k) {
+            const int idx = k * 64 + lane;
+            if (idx < G * H1V)
+                *reinterpret_cast<float4 *>(A + (idx / H1V) * LDA + 4 * (idx % H1V)) =
+                    *reinterpret_cast<const float4 *>(H1t + (idx / H1V) * LDH + 4 * (idx % H1V));
+        }
+        wave_lds_fence();
+        mma_tile<H1, NT2>(A, LDA, W1s_T, wl, r, q, acc_s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * q + i;
+            if (row < n_valid) {
+                float *dst = a.emb + (size_t)(w0 + row) * H2;
+#pragma unroll
+                for (int ct = 0; ct < NT2; ++ct) {           // an inner layer: through relu, no normalisation
+                    dst[ct * 16 + r] = fmaxf(acc_s[ct][i] + b1_T[ct * 16 + r], 0.f);
+                    dst[HH2 + ct * 16 + r] = fmaxf(acc_n[ct][i] + b1_T[HH2 + ct * 16 + r], 0.f);
+                }
+            }
+        }
+    }
+}
+
 template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB>
 __global__ __launch_bounds__(max_waves(HH1) * 64)
 void sage2_kernel(const Sage2Args a) {
@@ -552,7 +872,7 @@ void sage2_kernel(const Sage2Args a) {
     const bool has_work = p < a.n_pairs;
     // the root of a walk and its CSR row bounds are fetched one walk ahead; for the first walk that
     // is here, so the two dependent reads are in flight while the block stages the weights
-    int32_t root = has_work ? load_root(p) : -1;
+    int32_t root = (!SUB && has_work) ? load_root(p) : -1;
     int64_t ra = a.indptr[root >= 0 ? root : 0], rb = a.indptr[(root >= 0 ? root : 0) + 1];
 
     stage_weight(w0s_u, a.w0_self[0], FU, HH1);
@@ -571,6 +891,59 @@ void sage2_kernel(const Sage2Args a) {
     __syncthreads();
     if (!has_work) return;
 
+    if constexpr (SUB) {
+        // groups of kGroup consecutive roots; lane g < kGroup fetches root g's id, row bounds and walk id, one
+        // group ahead
+        const long long n_groups = (a.n_pairs + kGroup - 1) / kGroup;
+        auto fetch = [&](long long grp, int32_t &rv, int64_t &rav, int64_t &rbv, unsigned long long &wkv) {
+            const long long pr = grp * kGroup + min(lane, kGroup - 1);
+            const bool mine = grp < n_groups && pr < a.n_pairs;
+            const long long gi = base + min(pr, a.n_pairs - 1);
+            const long long seed = gi / a.sub_n;
+            wkv = a.walk_ids ? (unsigned long long)a.walk_ids[seed] : a.walk_base + (unsigned long long)seed;
+            if (a.seeds0) {
+                // the root is draw number gi % sub_n of its seed walk's first hop, as the sampler makes it
+                const unsigned slot = (unsigned)(gi - seed * a.sub_n);
+                int32_t sd = mine ? a.seeds0[seed] : -1;
+                if (mine && (unsigned long long)(long long)sd >= (unsigned long long)a.n_nodes) {
+                    if (lane < kGroup) atomicMax(&a.err[1], 1);
+                    sd = -1;
+                }
+                const int32_t sc = sd >= 0 ? sd : 0;
+                const int64_t sa = a.indptr[sc], sb = a.indptr[sc + 1];
+                const uint32_t deg = (uint32_t)(sb - sa);
+                const uint32_t rr = a.replay ? a.replay[(size_t)seed * a.tape_len + slot]
+                                             : gs::philox4x32_10_x((unsigned)wkv, (unsigned)(wkv >> 32), 0u, slot, a.key0, a.key1);
+                const bool live = sd >= 0 && deg != 0;
+                if (sd >= 0 && deg == 0 && lane < kGroup) atomicMax(&a.err[0], sd + 1);
+                rv = a.indices[live ? sa + (int64_t)__umulhi(rr, deg) : 0];
+                if (!live) rv = -1;
+                if (mine && lane < kGroup) a.hop1_out[gi] = rv;
+            } else {
+                rv = mine ? load_root(pr) : -1;
+            }
+            const int32_t rc = rv >= 0 ? rv : 0;
+            rav = a.indptr[rc];
+            rbv = a.indptr[rc + 1];
+        };
+        long long grp = (long long)(blockIdx.x >> 1) * n_waves + wave;
+        int32_t rv; int64_t rav, rbv; unsigned long long wkv;
+        fetch(grp, rv, rav, rbv, wkv);
+        for (; grp < n_groups; grp += stride) {
+            int32_t nrv; int64_t nrav, nrbv; unsigned long long nwkv;
+            fetch(grp + stride, nrv, nrav, nrbv, nwkv);
+            const int n_valid = (int)min((long long)kGroup, a.n_pairs - grp * kGroup);
+            if (side == 0)
+                group_body<FU, FI, HH1, HH2, LDA, LDH, BUF, kGroup>(a, base + grp * kGroup, n_valid, 0, lane, rv, rav, rbv, wkv, A, H1t, s_ids,
+                                                                    w0s_u, w0n_u, w0s_i, w0n_i, w1s, w1n, bias, bias + H1, bias + 2 * H1);
+            else
+                group_body<FI, FU, HH1, HH2, LDA, LDH, BUF, kGroup>(a, base + grp * kGroup, n_valid, 1, lane, rv, rav, rbv, wkv, A, H1t, s_ids,
+                                                                    w0s_i, w0n_i, w0s_u, w0n_u, w1s, w1n, bias + H1, bias, bias + 2 * H1);
+            rv = nrv; rav = nrav; rbv = nrbv; wkv = nwkv;
+        }
+        return;
+    }
+
     for (; p < a.n_pairs; p += stride) {
         const long long pn = p + stride;
         const int32_t next_root = pn < a.n_pairs ? load_root(pn) : -1;
@@ -588,9 +961,10 @@ void sage2_kernel(const Sage2Args a) {
 template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB = false>
 int launch_one(const Sage2Args &a, hipStream_t stream) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
+    constexpr int roots = SUB ? kGroup : 0;
     int waves = max_waves(HH1);                          // as many waves per CU as the LDS budget admits
-    while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves) > kLdsMax) waves -= 2;
-    const size_t lds = S::lds_bytes(a.n0, a.n1, waves);
+    while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves, roots) > kLdsMax) waves -= 2;
+    const size_t lds = S::lds_bytes(a.n0, a.n1, waves, roots);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
     auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF, SAVE, SUB>;
     static thread_local const void *configured = nullptr;
@@ -616,11 +990,11 @@ int launch(const Sage2Args &a, hipStream_t stream) {
 }
 
 // LDS of the smallest block this kernel runs with (4 waves)
-inline size_t sage2_lds(int Fu, int Fi, int H1, int H2, int n0, int n1) {
+inline size_t sage2_lds(int Fu, int Fi, int H1, int H2, int n0, int n1, int roots = 0) {
     const int fmax = Fu > Fi ? Fu : Fi, kmax = fmax > H1 ? fmax : H1;
-    const int ids = ((n0 + n0 * n1) + 3) & ~3;
+    const int ids = ((roots ? roots : 1) * (n0 + n0 * n1) + 3) & ~3;
     return (size_t)((Fu + Fi) * H1 + H1 * H2 + 2 * H1 + H2 +
-                    4 * (16 * (kmax + 4) + (1 + n0) * H1 + ids)) * sizeof(float);
+                    4 * (16 * (kmax + 4) + (roots ? roots : 1 + n0) * H1 + ids)) * sizeof(float);
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -658,7 +1032,7 @@ int sage2_forward_impl(const int64_t *indptr, const int32_t *indices, int64_t n_
 
     if (n_pairs < 0) return gs::fail(GS_EINVAL, "gs_sage2_forward: n_pairs=%lld", (long long)n_pairs);
     if (n_pairs == 0) return GS_OK;
-    if (!indptr || !indices || !feat_user || !feat_item || !seeds || !emb || !err_flag ||
+    if (!indptr || !indices || !feat_user || !feat_item || (!seeds && !(sub && sub->seeds)) || !emb || !err_flag ||
         !l0_user || !l0_item || !l1_user || !l1_item)
         return gs::fail(GS_EINVAL, "gs_sage2_forward: null pointer argument");
     const gs_sage_weights *ws[4] = {l0_user, l0_item, l1_user, l1_item};
@@ -690,6 +1064,14 @@ int sage2_forward_impl(const int64_t *indptr, const int32_t *indices, int64_t n_
         a.n_pairs = n_pairs * sub->roots_per_walk;           // roots per node type
         a.tape_len = sub->tape_len; a.tape_off0 = sub->tape_off_hop2; a.tape_off1 = sub->tape_off_hop3;
         a.out_h0 = sub->out_h0;
+        a.seeds0 = sub->seeds; a.hop1_out = sub->out_hop1;
+        if (sub->seeds && !sub->out_hop1)
+            return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: seeds given without out_hop1");
+        if (sub->seeds && replay && sub->roots_per_walk > sub->tape_len)
+            return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: the hops do not fit a tape of %lld words per walk", (long long)sub->tape_len);
+        if ((long long)kGroup * n0 * n1 > 4096 ||
+            sage2_lds(Fu, Fi, H1, H2, n0, n1, kGroup) > kLdsMax)
+            return gs::fail(GS_ELIMIT, "gs_sage2_forward_subtrees: fan-outs [%d,%d] are too large for %d subtrees per wavefront", n0, n1, kGroup);
     }
     a.key0 = (unsigned)rng_seed; a.key1 = (unsigned)(rng_seed >> 32); a.walk_base = walk_id_base;
     a.walk_ids = walk_ids; a.replay = replay;
@@ -698,8 +1080,8 @@ int sage2_forward_impl(const int64_t *indptr, const int32_t *indices, int64_t n_
     a.w1_self[0] = l1_user->w_self; a.w1_neigh[0] = l1_user->w_neigh; a.b1[0] = l1_user->bias;
     a.w1_self[1] = l1_item->w_self; a.w1_neigh[1] = l1_item->w_neigh; a.b1[1] = l1_item->bias;
     a.normalize = sub ? 0 : normalize; a.emb = emb; a.out_hop1 = out_hop1; a.out_hop2 = out_hop2; a.err = err_flag;
-    a.ids_per_wave = ((n0 + n0 * n1) + 3) & ~3;
-    a.h1_rows = 1 + n0;
+    a.ids_per_wave = ((sub ? kGroup : 1) * (n0 + n0 * n1) + 3) & ~3;
+    a.h1_rows = sub ? kGroup : 1 + n0;
     if (saved) {
         for (int t = 0; t < 2; ++t) {
             if ((!saved->x_self[t] && !saved->self_ids[t]) || !saved->x_mean[t] || !saved->h1[t] || !saved->x_mean1[t] || !saved->z[t])
@@ -756,4 +1138,335 @@ extern "C" int gs_sage2_forward_subtrees(const int64_t *indptr, const int32_t *i
     return sage2_forward_impl(indptr, indices, n_nodes, feat_user, n_users, Fu, feat_item, n_items, Fi, hop1_ids, n_pairs, n1, n2,
                               rng_seed, walk_id_base, walk_ids, replay, l0_user, l0_item, l1_user, l1_item, H1, H2, 0,
                               h1_out, out_hop2, out_hop3, nullptr, sub, err_flag, stream);
+}
+
+// ---- the seed nodes of a three-hop model -------------------------------------------------------------
+// What is left above the subtree kernel: layers 0, 1 and 2 at the seeds, whose neighbors are the hop-1
+// nodes -- their feature rows (layer 0), their layer-0 outputs (layer 1) and their layer-1 outputs (layer 2).
+// One launch for both node types; a wavefront takes kSeedsPerWave seeds through all three layers (rows
+// 0 .. kSeedsPerWave-1 of the 16-row MFMA tile: few seeds per wave because the launch is short and lives on
+// having many waves' row loads in flight, not on the matrix pipe).
+namespace {
+
+constexpr int kSeedsPerWave = 4;
+constexpr int kSeedWaves = 8;
+
+struct Roots3Args {
+    const float *feat[2]; long long n_rows[2];
+    const int32_t *seeds, *hop1; long long n_pairs, n_nodes; int n0;
+    const float *h0, *h1;                              // [2*n_pairs*n0, H1] / [.., H2]: rows as hop1
+    const float *ws[3][2], *wn[3][2], *b[3][2];        // by layer and seed type
+    int act, normalize;
+    float *emb;                                        // [2*n_pairs, H3]
+};
+
+// Sums of the n rows (4*V floats each) of R heads, divided by n, into rows 0 .. R-1 of A.  A load instruction
+// covers 64 / V rows; with at least R of them a head's rows are split over GPS lane groups, whose partial sums
+// are added at the end.  load(g, j, c, ok): 16 bytes at column chunk c of row j of head g (zeros unless ok).
+template <int V, int R, typename Load>
+__device__ __forceinline__ void head_means(int lane, int n, float *A, int lda, Load load) {
+    constexpr int GN = 64 / V;
+    constexpr int GPS = GN >= R ? GN / R : 1;
+    constexpr int SPP = GN >= R ? R : GN;
+    constexpr int kU = 13;
+    const int gi = lane / V, c = lane % V, u = gi % GPS;
+    const float d = (float)n;
+#pragma unroll
+    for (int p = 0; p < R / SPP; ++p) {
+        const int g = p * SPP + gi / GPS;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int jb = 0; jb < n; jb += kU * GPS) {
+            float4 v[kU];
+#pragma unroll
+            for (int t = 0; t < kU; ++t) {
+                const int j = jb + u + t * GPS;
+                v[t] = load(g, min(j, n - 1), c, j < n);
+            }
+#pragma unroll
+            for (int t = 0; t < kU; ++t) { s.x += v[t].x; s.y += v[t].y; s.z += v[t].z; s.w += v[t].w; }
+        }
+#pragma unroll
+        for (int m = V; m < V * GPS; m <<= 1) {
+            s.x += __shfl_xor(s.x, m, 64); s.y += __shfl_xor(s.y, m, 64);
+            s.z += __shfl_xor(s.z, m, 64); s.w += __shfl_xor(s.w, m, 64);
+        }
+        if (u == 0) *reinterpret_cast<float4 *>(A + g * lda + 4 * c) = make_float4(s.x / d, s.y / d, s.z / d, s.w / d);
+    }
+}
+
+template <int FT, int FO, int HH1, int HH2, int HH3, int LDA, int LDS_H>
+__device__ __forceinline__ void seeds_body(const Roots3Args &a, long long tile, int side, int lane,
+                                           float *A, float *Hs, int32_t *ids,
+                                           const float *w0s, const float *w0n, const float *w1s, const float *w1n,
+                                           const float *w2s, const float *w2n,
+                                           const float *b0, const float *b1, const float *b2) {
+    constexpr int R = kSeedsPerWave;
+    constexpr int NT1 = HH1 / 16, NT2 = HH2 / 16, NT3 = HH3 / 16, H1 = 2 * HH1, H2 = 2 * HH2, H3 = 2 * HH3;
+    constexpr int FTV = FT / 4, FOV = FO / 4, H1V = H1 / 4, H2V = H2 / 4;
+    constexpr int RT_N = (R * FTV + 63) / 64;
+    const int r = lane & 15, q = lane >> 4;
+    const int n0 = a.n0;
+    RowTable<false> tabT, tabO;
+    tabT.init(a.feat[side], a.n_rows[side], FT * 4);
+    tabO.init(a.feat[1 - side], a.n_rows[1 - side], FO * 4);
+    const int offT = side ? (int)a.n_rows[0] : 0, offO = side ? 0 : (int)a.n_rows[0];
+    int wl = lane;
+    asm volatile("" : "+v"(wl));
+    const long long s0 = tile * R;                     // first seed of the tile, within its type
+    const long long row0 = (long long)side * a.n_pairs + s0;       // its row in the seed-ordered arrays
+
+    wave_lds_fence();                                  // the previous tile's readers are done
+    for (int i = lane; i < R * n0; i += 64) {
+        const int g = i / n0;
+        ids[i] = s0 + g < a.n_pairs ? a.hop1[row0 * n0 + i] : -1;
+    }
+    float4 own[RT_N];
+#pragma unroll
+    for (int k = 0; k < RT_N; ++k) {
+        const int idx = k * 64 + lane, g = min(idx / FTV, R - 1), c = idx % FTV;
+        const bool ok = idx < R * FTV && s0 + g < a.n_pairs;
+        const int32_t sd = ok ? a.seeds[row0 + g] : -1;
+        own[k] = tabT.load(ok && (unsigned long long)(long long)sd < (unsigned long long)a.n_nodes,
+                           (unsigned)(sd - offT), (unsigned)c * 16u, FT * 4);
+    }
+    wave_lds_fence();
+
+    // ---- layer 0: neighbors = the hop-1 nodes' feature rows ----
+    head_means<FOV, R>(lane, n0, A, LDA, [&](int g, int j, int c, bool ok) {
+        const int32_t id = ids[g * n0 + j];
+        return tabO.load(ok && id >= 0, (unsigned)(id - offO), (unsigned)c * 16u, FO * 4);
+    });
+    wave_lds_fence();
+    {
+        f32x4 acc_s[NT1], acc_n[NT1];
+#pragma unroll
+        for (int ct = 0; ct < NT1; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_tile<FO, NT1>(A, LDA, w0n, wl, r, q, acc_n);
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < RT_N; ++k) {
+            const int idx = k * 64 + lane;
+            if (idx < R * FTV) *reinterpret_cast<float4 *>(A + (idx / FTV) * LDA + 4 * (idx % FTV)) = own[k];
+        }
+        wave_lds_fence();
+        mma_tile<FT, NT1>(A, LDA, w0s, wl, r, q, acc_s);
+        if (q == 0) {                                  // rows 0 .. 3 of D: registers 0 .. 3 of lanes 0 .. 15
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int ct = 0; ct < NT1; ++ct) {
+                    Hs[i * LDS_H + ct * 16 + r] = fmaxf(acc_s[ct][i] + b0[ct * 16 + r], 0.f);
+                    Hs[i * LDS_H + HH1 + ct * 16 + r] = fmaxf(acc_n[ct][i] + b0[HH1 + ct * 16 + r], 0.f);
+                }
+        }
+        wave_lds_fence();
+    }
+
+    // ---- layer 1: neighbors = the hop-1 nodes' layer-0 outputs (consecutive rows) ----
+    head_means<H1V, R>(lane, n0, A, LDA, [&](int g, int j, int c, bool ok) {
+        const bool want = ok && s0 + g < a.n_pairs;
+        const float4 t = *reinterpret_cast<const float4 *>(a.h0 + ((size_t)(row0 + (want ? g : 0)) * n0 + j) * H1 + 4 * c);
+        return want ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    });
+    wave_lds_fence();
+    {
+        f32x4 acc_s[NT2], acc_n[NT2];
+#pragma unroll
+        for (int ct = 0; ct < NT2; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_tile<H1, NT2>(A, LDA, w1n, wl, r, q, acc_n);
+        wave_lds_fence();
+        if (lane < R * H1V)
+            *reinterpret_cast<float4 *>(A + (lane / H1V) * LDA + 4 * (lane % H1V)) =
+                *reinterpret_cast<const float4 *>(Hs + (lane / H1V) * LDS_H + 4 * (lane % H1V));
+        wave_lds_fence();
+        mma_tile<H1, NT2>(A, LDA, w1s, wl, r, q, acc_s);
+        if (q == 0) {
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int ct = 0; ct < NT2; ++ct) {
+                    Hs[i * LDS_H + ct * 16 + r] = fmaxf(acc_s[ct][i] + b1[ct * 16 + r], 0.f);
+                    Hs[i * LDS_H + HH2 + ct * 16 + r] = fmaxf(acc_n[ct][i] + b1[HH2 + ct * 16 + r], 0.f);
+                }
+        }
+        wave_lds_fence();
+    }
+
+    // ---- layer 2: neighbors = the hop-1 nodes' layer-1 outputs ----
+    head_means<H2V, R>(lane, n0, A, LDA, [&](int g, int j, int c, bool ok) {
+        const bool want = ok && s0 + g < a.n_pairs;
+        const float4 t = *reinterpret_cast<const float4 *>(a.h1 + ((size_t)(row0 + (want ? g : 0)) * n0 + j) * H2 + 4 * c);
+        return want ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    });
+    wave_lds_fence();
+    {
+        f32x4 acc_s[NT3], acc_n[NT3];
+#pragma unroll
+        for (int ct = 0; ct < NT3; ++ct) { acc_s[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_n[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        mma_tile<H2, NT3>(A, LDA, w2n, wl, r, q, acc_n);
+        wave_lds_fence();
+        if (lane < R * H2V)
+            *reinterpret_cast<float4 *>(A + (lane / H2V) * LDA + 4 * (lane % H2V)) =
+                *reinterpret_cast<const float4 *>(Hs + (lane / H2V) * LDS_H + 4 * (lane % H2V));
+        wave_lds_fence();
+        mma_tile<H2, NT3>(A, LDA, w2s, wl, r, q, acc_s);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            float o[2][NT3];
+            float ss = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NT3; ++ct) {
+                o[0][ct] = acc_s[ct][i] + b2[ct * 16 + r];
+                o[1][ct] = acc_n[ct][i] + b2[HH3 + ct * 16 + r];
+                if (a.act == GS_ACT_RELU) { o[0][ct] = fmaxf(o[0][ct], 0.f); o[1][ct] = fmaxf(o[1][ct], 0.f); }
+                ss += o[0][ct] * o[0][ct] + o[1][ct] * o[1][ct];
+            }
+            if (a.normalize) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m, 64);
+                const float inv = rsqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+                for (int ct = 0; ct < NT3; ++ct) { o[0][ct] *= inv; o[1][ct] *= inv; }
+            }
+            if (q == 0 && s0 + i < a.n_pairs) {
+                float *dst = a.emb + (size_t)(row0 + i) * H3;
+#pragma unroll
+                for (int ct = 0; ct < NT3; ++ct) { dst[ct * 16 + r] = o[0][ct]; dst[HH3 + ct * 16 + r] = o[1][ct]; }
+            }
+        }
+    }
+}
+
+template <int FU, int FI, int HH1, int HH2, int HH3>
+struct Roots3Shape {
+    static constexpr int H1 = 2 * HH1, H2 = 2 * HH2, H3 = 2 * HH3;
+    static constexpr int FMAX = FU > FI ? FU : FI, HMAX = H1 > H2 ? H1 : H2;
+    static constexpr int LDA = (FMAX > HMAX ? FMAX : HMAX) + 4;
+    static constexpr int W_FLOATS = (FU + FI) * HH1 + 2 * H1 * HH2 + 2 * H2 * HH3 + H1 + H2 + H3;
+    static size_t lds_bytes(int n0) {
+        const int ids = (kSeedsPerWave * n0 + 3) & ~3;
+        return (size_t)(W_FLOATS + kSeedWaves * (16 * LDA + kSeedsPerWave * HMAX + ids)) * sizeof(float);
+    }
+};
+
+template <int FU, int FI, int HH1, int HH2, int HH3>
+__global__ __launch_bounds__(kSeedWaves * 64)
+void sage3_seeds_kernel(const Roots3Args a) {
+    using S = Roots3Shape<FU, FI, HH1, HH2, HH3>;
+    constexpr int H1 = S::H1, H2 = S::H2, H3 = S::H3, LDA = S::LDA, HMAX = S::HMAX;
+    extern __shared__ float lds[];
+    const int side = blockIdx.x & 1;                   // even blocks: the user seeds
+    const int FT = side ? FI : FU, FO = side ? FU : FI;
+    float *w0s = lds;
+    float *w0n = w0s + FT * HH1;
+    float *w1s = w0n + FO * HH1;
+    float *w1n = w1s + H1 * HH2;
+    float *w2s = w1n + H1 * HH2;
+    float *w2n = w2s + H2 * HH3;
+    float *bias = w2n + H2 * HH3;                      // b0[H1] b1[H2] b2[H3]
+    float *wave0 = bias + H1 + H2 + H3;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ids_n = (kSeedsPerWave * a.n0 + 3) & ~3;
+    const int per_wave = 16 * LDA + kSeedsPerWave * HMAX + ids_n;
+    float *A = wave0 + (size_t)wave * per_wave;
+    float *Hs = A + 16 * LDA;
+    int32_t *ids = reinterpret_cast<int32_t *>(Hs + kSeedsPerWave * HMAX);
+    stage_weight(w0s, a.ws[0][side], FT, HH1);
+    stage_weight(w0n, a.wn[0][side], FO, HH1);
+    stage_weight(w1s, a.ws[1][side], H1, HH2);
+    stage_weight(w1n, a.wn[1][side], H1, HH2);
+    stage_weight(w2s, a.ws[2][side], H2, HH3);
+    stage_weight(w2n, a.wn[2][side], H2, HH3);
+    for (int i = threadIdx.x; i < H1 + H2 + H3; i += blockDim.x) {
+        const float *src = i < H1 ? a.b[0][side] : i < H1 + H2 ? a.b[1][side] : a.b[2][side];
+        const int k = i < H1 ? i : i < H1 + H2 ? i - H1 : i - H1 - H2;
+        bias[i] = src ? src[k] : 0.f;
+    }
+    __syncthreads();
+    const long long tiles = (a.n_pairs + kSeedsPerWave - 1) / kSeedsPerWave;
+    const long long my_blocks = (gridDim.x + 1 - side) >> 1;
+    for (long long tile = (long long)(blockIdx.x >> 1) * kSeedWaves + wave; tile < tiles; tile += my_blocks * kSeedWaves) {
+        if (side == 0)
+            seeds_body<FU, FI, HH1, HH2, HH3, LDA, HMAX>(a, tile, 0, lane, A, Hs, ids, w0s, w0n, w1s, w1n, w2s, w2n,
+                                                         bias, bias + H1, bias + H1 + H2);
+        else
+            seeds_body<FI, FU, HH1, HH2, HH3, LDA, HMAX>(a, tile, 1, lane, A, Hs, ids, w0s, w0n, w1s, w1n, w2s, w2n,
+                                                         bias, bias + H1, bias + H1 + H2);
+    }
+}
+
+template <int FU, int FI, int HH1, int HH2, int HH3>
+int launch_seeds(const Roots3Args &a, hipStream_t stream) {
+    using S = Roots3Shape<FU, FI, HH1, HH2, HH3>;
+    const size_t lds = S::lds_bytes(a.n0);
+    if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage3_seeds_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
+    auto kern = sage3_seeds_kernel<FU, FI, HH1, HH2, HH3>;
+    static thread_local const void *configured = nullptr;
+    if (lds > 64 * 1024 && configured != (const void *)kern) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+        if (e != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage3_seeds_forward: cannot raise the LDS limit: %s", hipGetErrorString(e));
+        configured = (const void *)kern;
+    }
+    const long long tiles = (a.n_pairs + kSeedsPerWave - 1) / kSeedsPerWave;
+    long long blocks = 2 * ((tiles + kSeedWaves - 1) / kSeedWaves);
+    if (blocks > 1024) blocks = 1024;
+    gs::launch_timed(kern, dim3((unsigned)blocks), dim3(kSeedWaves * 64), lds, stream, a);
+    return gs::check_launch("gs_sage3_seeds_forward");
+}
+
+}  // namespace
+
+extern "C" int gs_sage3_seeds_supported(int Fu, int Fi, int H1, int H2, int H3, int n0) {
+    if (n0 < 1 || n0 > 4096 || (H3 != 32 && H3 != 64)) return 0;
+    bool found = false;
+#define GS_X(fu, fi, a1, a2) found = found || (Fu == fu && Fi == fi && H1 == 2 * a1 && H2 == 2 * a2);
+    GS_SAGE2_CASES(GS_X)
+#undef GS_X
+    if (!found) return 0;
+    const int fmax = Fu > Fi ? Fu : Fi, hmax = H1 > H2 ? H1 : H2, lda = (fmax > hmax ? fmax : hmax) + 4;
+    const size_t lds = (size_t)((Fu + Fi) * (H1 / 2) + H1 * H2 + H2 * H3 + H1 + H2 + H3 +
+                                kSeedWaves * (16 * lda + kSeedsPerWave * hmax + ((kSeedsPerWave * n0 + 3) & ~3))) * sizeof(float);
+    return lds <= kLdsMax;
+}
+
+extern "C" int gs_sage3_seeds_forward(const float *feat_user, int64_t n_users, int Fu,
+                                      const float *feat_item, int64_t n_items, int Fi,
+                                      const int32_t *seeds, int64_t n_pairs, const int32_t *hop1_ids, int n0,
+                                      const float *h0_hop1, const float *h1_hop1,
+                                      const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                                      const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                                      const gs_sage_weights *l2_user, const gs_sage_weights *l2_item,
+                                      int H1, int H2, int H3, int act, int normalize, float *emb, void *stream) {
+    if (n_pairs < 0) return gs::fail(GS_EINVAL, "gs_sage3_seeds_forward: n_pairs=%lld", (long long)n_pairs);
+    if (n_pairs == 0) return GS_OK;
+    const gs_sage_weights *ws[6] = {l0_user, l0_item, l1_user, l1_item, l2_user, l2_item};
+    if (!feat_user || !feat_item || !seeds || !hop1_ids || !h0_hop1 || !h1_hop1 || !emb)
+        return gs::fail(GS_EINVAL, "gs_sage3_seeds_forward: null pointer argument");
+    for (int i = 0; i < 6; ++i)
+        if (!ws[i] || !ws[i]->w_self || !ws[i]->w_neigh)
+            return gs::fail(GS_EINVAL, "gs_sage3_seeds_forward: weight set %d is null or has a null matrix", i);
+    if (n_users < 1 || n_items < 1 || n_users + n_items > 0x7FFFFFFELL)
+        return gs::fail(GS_EINVAL, "gs_sage3_seeds_forward: n_users=%lld n_items=%lld out of range", (long long)n_users, (long long)n_items);
+    if (act != GS_ACT_LINEAR && act != GS_ACT_RELU) return gs::fail(GS_EINVAL, "gs_sage3_seeds_forward: unknown activation %d", act);
+    if (!aligned16(feat_user) || !aligned16(feat_item) || !aligned16(h0_hop1) || !aligned16(h1_hop1))
+        return gs::fail(GS_EINVAL, "gs_sage3_seeds_forward: feature tables and activation rows must be 16-byte aligned");
+    if (!gs_sage3_seeds_supported(Fu, Fi, H1, H2, H3, n0))
+        return gs::fail(GS_ELIMIT, "gs_sage3_seeds_forward: shape Fu=%d Fi=%d H1=%d H2=%d H3=%d fan-out %d is outside this kernel's "
+                                   "range; use gs_sage_fused_fwd per layer", Fu, Fi, H1, H2, H3, n0);
+    Roots3Args a{};
+    a.feat[0] = feat_user; a.feat[1] = feat_item; a.n_rows[0] = n_users; a.n_rows[1] = n_items;
+    a.seeds = seeds; a.hop1 = hop1_ids; a.n_pairs = n_pairs; a.n_nodes = n_users + n_items; a.n0 = n0;
+    a.h0 = h0_hop1; a.h1 = h1_hop1;
+    for (int l = 0; l < 3; ++l)
+        for (int t = 0; t < 2; ++t) {
+            a.ws[l][t] = ws[2 * l + t]->w_self; a.wn[l][t] = ws[2 * l + t]->w_neigh; a.b[l][t] = ws[2 * l + t]->bias;
+        }
+    a.act = act; a.normalize = normalize; a.emb = emb;
+    hipStream_t s = (hipStream_t)stream;
+    const int hh1 = H1 / 2, hh2 = H2 / 2;
+#define GS_X(fu, fi, a1, a2) if (Fu == fu && Fi == fi && hh1 == a1 && hh2 == a2) \
+        return H3 == 32 ? launch_seeds<fu, fi, a1, a2, 16>(a, s) : launch_seeds<fu, fi, a1, a2, 32>(a, s);
+    GS_SAGE2_CASES(GS_X)
+#undef GS_X
+    return gs::fail(GS_ELIMIT, "gs_sage3_seeds_forward: no instantiation for Fu=%d Fi=%d H1=%d H2=%d", Fu, Fi, H1, H2);
 }

@@ -31,7 +31,7 @@ _TYPES = ('user', 'item')
 
 class SageForwardEngine:
     def __init__(self, graph, model, batch_size, use_fused=True, walk_kernel=True, keep_ids=False, draw_in_layer=False,
-                 wide_min_rows=128 * 256, subtree_kernel=False):
+                 wide_min_rows=128 * 256, subtree_kernel=True):
         """draw_in_layer: the layer-0 kernel draws the deepest hop's ids itself instead of reading what
         the sampler kernel wrote (``gs_sage_fused_sampled_fwd``); keep_ids then also leaves those ids
         in ``hops[-1]``.  Off by default: a draw costs one 64-byte sector of the neighbor array wherever
@@ -128,15 +128,17 @@ class SageForwardEngine:
                 self._padded = {'tables': tabs, 'weights': wts, 'fresh': False}
                 self.walk_kernel = True
         self._walk_call = None
-        # three hops, on request: the same kernel below the first hop -- one wavefront per hop-1 node draws hops 2
-        # and 3 and computes layers 0 and 1 of its subtree -- then three small launches per node type for the
-        # roots.  Off by default: a subtree of fan-outs [10, 5] is 61 rows behind seven dependent round trips, and
-        # sixteen wavefronts per compute unit do not hide those (cfg-2 graph, [25,10,5]: 1.11 ms per step against
-        # 0.76 ms for the sampler + one kernel per layer and type).
+        # Three hops at the widths of the one-kernel forward: two launches.  The same kernel below the seeds -- a
+        # wavefront takes eight hop-1 nodes at a time, draws them and their subtrees' hops 2 and 3 and computes
+        # layers 0 and 1 per subtree -- then one kernel for layers 0, 1, 2 at the seeds.  (cfg-2 graph,
+        # [25,10,5]: 0.62 ms per step against 0.76 ms for the sampler + one kernel per layer and type.)
         self.subtree_kernel = bool(
             subtree_kernel and use_fused and walk_kernel and self.n_hops == 3 and all(self.fused_layers) and not self.wide_first_layer_only
-            and model.dims[1]['user'] == model.dims[1]['item'] and model.dims[2]['user'] == model.dims[2]['item']
-            and kernels.sage2_supported(f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'], *self.fanouts[1:]))
+            and all(model.dims[l]['user'] == model.dims[l]['item'] for l in (1, 2, 3))
+            and model._aggs[2]['user'].activation == model._aggs[2]['item'].activation
+            and kernels.sage2_supported(f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'], *self.fanouts[1:])
+            and kernels.sage3_seeds_supported(f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'],
+                                              model.dims[3]['user'], self.fanouts[0]))
         self._subtree = None
         self.emb_all = torch.empty((2 * b, model.dims[-1]['user']), dtype=torch.float32, device=device)
         # On request (draw_in_layer) the deepest hop -- most of a walk's samples -- is drawn by the
@@ -390,10 +392,8 @@ class SageForwardEngine:
         return self.emb_all[:self.batch], self.emb_all[self.batch:]
 
     def forward_subtrees(self, seeds, walk_ids=None, rng_seed=0, replay=None):
-        """Three hops: hop 1 from the sampler, everything below a hop-1 node in one kernel (hops 2 and 3 drawn,
-        layers 0 and 1 computed per subtree), then layers 0, 1, 2 at the roots."""
-        import ctypes
-        from ._lib import check, load, ptr, stream_handle
+        """Three hops in two launches: everything below the seeds in one kernel (all three hops drawn, layers 0 and
+        1 computed per hop-1 node's subtree), then layers 0, 1, 2 at the seeds in a second one."""
         m, b, other = self.model, self.batch, self.other
         n0, n1, n2 = self.fanouts
         if seeds.numel() != 2 * b or seeds.dtype != torch.int32 or not seeds.is_cuda:
@@ -407,54 +407,26 @@ class SageForwardEngine:
             dev = self.indptr.device
             h1w, h2w = m.dims[1]['user'], m.dims[2]['user']
             st = {'h0': torch.empty((2 * b * n0, h1w), dtype=torch.float32, device=dev),       # layer 0 at the hop-1 nodes
-                  'h1': torch.empty((2 * b * n0, h2w), dtype=torch.float32, device=dev),       # layer 1 at the hop-1 nodes
-                  'root_h0': {t: torch.empty((b, h1w), dtype=torch.float32, device=dev) for t in _TYPES},
-                  'root_h1': {t: torch.empty((b, h2w), dtype=torch.float32, device=dev) for t in _TYPES}}
+                  'h1': torch.empty((2 * b * n0, h2w), dtype=torch.float32, device=dev)}       # layer 1 at the hop-1 nodes
             weights = {(l, t): (m._aggs[l][t].w_self, m._aggs[l][t].w_neigh, m._aggs[l][t].bias)
-                       for l in (0, 1) for t in _TYPES}
+                       for l in (0, 1, 2) for t in _TYPES}
             st['call'] = kernels.Sage2Call(
-                self.indptr, self.indices, self.tables['user'][0], self.tables['item'][0], [n1, n2], weights, False, b,
+                self.indptr, self.indices, self.tables['user'][0], self.tables['item'][0], [n1, n2],
+                {k: w for k, w in weights.items() if k[0] < 2}, False, b,
                 emb=st['h1'], hop_buffers=(self.hops[1], self.hops[2]) if self.keep_ids else None,
                 subtrees={'roots_per_walk': n0, 'tape_len': tape_len, 'tape_off_hop2': self.sizes[1],
-                          'tape_off_hop3': self.sizes[1] + self.sizes[2], 'out_h0': st['h0']})
-            st['fan'] = (ctypes.c_int32 * 1)(n0)
-            st['hop_ptr'] = (ctypes.c_void_p * 1)(self.hops[0].data_ptr())
-            # the roots: side 0 = user-rooted walks (rows [0, b) of the hop tables, their hop-1 nodes are items)
-            calls = {}
-            for side, t in enumerate(_TYPES):
-                a0, a1, a2 = (m._aggs[l][t] for l in range(3))
-                (f_self, o_self), (f_neigh, o_neigh) = self.tables[t], self.tables[other[t]]
-                kids0 = {'n_heads': b, 'n_child': n0, 'self_row0': 0, 'child_row0': side * b * n0}
-                calls[(0, t)] = kernels.FusedLayerCall(
-                    f_self, o_self, f_neigh, o_neigh,
-                    [{'head_ids': self._slot_ids(self.seeds_buf, 0, side), 'child_ids': self._slot_ids(self.seeds_buf, 1, side),
-                      'n_heads': b, 'n_child': n0}], a0.w_self, a0.w_neigh, a0.bias, a0.activation, False, st['root_h0'][t])
-                calls[(1, t)] = kernels.FusedLayerCall(st['root_h0'][t], 0, st['h0'], 0, [kids0], a1.w_self, a1.w_neigh, a1.bias,
-                                                       a1.activation, False, st['root_h1'][t])
-                calls[(2, t)] = kernels.FusedLayerCall(st['root_h1'][t], 0, st['h1'], 0, [kids0], a2.w_self, a2.w_neigh, a2.bias,
-                                                       a2.activation, m.normalize == "l2", self.emb[t])
-            st['calls'] = calls
+                          'tape_off_hop3': self.sizes[1] + self.sizes[2], 'out_h0': st['h0'],
+                          'draw_hop1': self.hops[0].reshape(-1)})
+            st['seeds'] = kernels.Sage3SeedsCall(
+                self.tables['user'][0], self.tables['item'][0], self.hops[0].reshape(-1), n0, st['h0'], st['h1'], weights,
+                m._aggs[2]['user'].activation, m.normalize == "l2", b, self.emb_all)
             self._subtree = st
         st = self._subtree
-        lib = load()
-        tape1 = None
-        if replay is not None:                               # the sampler strides the tape by ITS hops' words
-            tape1 = replay.reshape(seeds.numel(), tape_len)[:, :n0].contiguous().reshape(-1)
-        check(lib.gs_sample(ptr(self.indptr), ptr(self.indices), self.indptr.numel() - 1, ptr(seeds), seeds.numel(),
-                            st['fan'], 1, int(rng_seed) & 0xFFFFFFFFFFFFFFFF, 0, ptr(walk_ids), ptr(tape1), st['hop_ptr'],
-                            ptr(self.err_flag), stream_handle()), 'gs_sample')
         if self.probes is not None:
             self._arm_probe()
-        st['call'].run(self.hops[0].reshape(-1), self.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
-        for layer in range(3):
-            for side, t in enumerate(_TYPES):
-                call = st['calls'][(layer, t)]
-                if layer == 0:
-                    call.set_head_ids(0, self._slot_ids(seeds, 0, side))
-                call.run()
-        if m.normalize != "l2":
-            pass                                             # (layer 2 wrote self.emb without the normalisation)
-        return self.emb['user'], self.emb['item']
+        st['call'].run(seeds, self.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
+        st['seeds'].run(seeds)
+        return self.emb_all[:b], self.emb_all[b:]
 
     def forward(self, seeds, walk_ids=None, rng_seed=0, replay=None):
         if self.walk_kernel:
@@ -471,8 +443,8 @@ class SageForwardEngine:
         if self.walk_kernel:
             return "sage2_kernel (sample + both layers + l2norm, one wavefront per walk)"
         if self.subtree_kernel:
-            return ("sage2_kernel below the first hop (hops 2 and 3 drawn, layers 0 and 1 of every hop-1 node's "
-                    "subtree, one wavefront per subtree)")
+            return ("sage2_kernel below the seeds (all three hops drawn, layers 0 and 1 of every hop-1 node's "
+                    "subtree, eight subtrees per wavefront at a time)")
         if self.use_fused and all(self.fused_layers):
             if self.wide_first_layer_only:
                 return ("sage_wide_kernel (layer 0: neighbor gather + mean on producer waves beside the MFMA "
@@ -500,7 +472,7 @@ class SageForwardEngine:
         if self.walk_kernel:
             # the one-kernel forward: CSR reads as the sampler's accounting (without the id
             # round trip), every sampled node's feature row once, one embedding row per root
-            sampler, agg = self.algorithmic_bytes()
+            sampler, agg = self._layered_bytes()
             samples = 2 * sum(self.sizes[1:])
             rows = sum(b * self.sizes[hh] * f[_TYPES[(side + hh) % 2]] * 4
                        for hh in range(self.n_hops + 1) for side in range(2))
@@ -508,13 +480,14 @@ class SageForwardEngine:
         if self.subtree_kernel:
             # per hop-1 node: its id, the CSR reads of its subtree's draws (row bounds of 1 + n1 expanded nodes, one
             # neighbor word per draw), every subtree node's feature row once, its two output rows
+            # (its own draw: one neighbor word read, the id written; per seed walk the seed id and its row bounds)
             n0, n1, n2 = self.fanouts
             per_root = {}
             for side, t in enumerate(_TYPES):               # t = type of the subtree's root
                 o = self.other[t]
                 rows = f[t] * 4 * (1 + n1 * n2) + f[o] * 4 * n1
-                per_root[t] = 4 + 16 * (1 + n1) + 4 * (n1 + n1 * n2) + rows + 4 * (self.model.dims[1][t] + self.model.dims[2][t])
-            return b * n0 * sum(per_root.values())
+                per_root[t] = 8 + 16 * (1 + n1) + 4 * (n1 + n1 * n2) + rows + 4 * (self.model.dims[1][t] + self.model.dims[2][t])
+            return b * n0 * sum(per_root.values()) + 2 * b * (4 + 16)
         if self.use_fused and all(self.fused_layers):
             # fused layer 0, one launch per head type: head + child ids read, one feature row per
             # head and per child read, one output row per head written
@@ -579,10 +552,21 @@ class SageForwardEngine:
 
     # algorithmic bytes of one step, per the accounting used for the roofline
     def algorithmic_bytes(self):
-        """(sampler bytes, gather+aggregate bytes) one batch must move at least:
-        ids and CSR row bounds read, sampled ids written; every sampled node's
-        feature row read once and the layer-0 inputs (own row + neighbor mean
-        per head node) written once."""
+        """(sampler bytes, gather+aggregate bytes) one batch must move at least on the route this engine takes.
+        Layered routes: ids and CSR row bounds read, sampled ids written; every sampled node's feature row read
+        once and the layer-0 inputs (own row + neighbor mean per head node) written once.  The one- and
+        two-launch routes write neither ids nor layer inputs: their kernels' own accounting."""
+        if self.walk_kernel:
+            return 0, self.dominant_bytes()
+        if self.subtree_kernel:
+            b, f, d = self.batch, self.graph.node_feature_sizes, self.model.dims
+            n0 = self.fanouts[0]
+            seeds = sum(4 + 4 * n0 + 4 * f[t] + 4 * n0 * f[self.other[t]] + 4 * n0 * (d[1][t] + d[2][t]) + 4 * d[3][t]
+                        for t in _TYPES)
+            return 0, self.dominant_bytes() + b * seeds
+        return self._layered_bytes()
+
+    def _layered_bytes(self):
         b = self.batch
         f = self.graph.node_feature_sizes
         sizes = self.sizes

@@ -721,7 +721,9 @@ class Sage2Call:
         ``subtrees`` = {'roots_per_walk': R, 'tape_len', 'tape_off_hop2', 'tape_off_hop3', 'out_h0'
         (tensor (2*n_pairs*R, H1) or None)}: ``gs_sage2_forward_subtrees`` -- the roots given to
         ``run`` are the 2*n_pairs*R hop-1 nodes of a three-hop model's walks, ``fanouts`` those of
-        hops 2 and 3, ``emb`` (2*n_pairs*R, H2) receives relu(layer 1) at every root.
+        hops 2 and 3, ``emb`` (2*n_pairs*R, H2) receives relu(layer 1) at every root.  With
+        'draw_hop1': int32 tensor (2*n_pairs*R) the kernel draws hop 1 too: ``run`` then takes the
+        2*n_pairs seed nodes and the hop-1 ids are written to that tensor.
         ``hop_buffers`` = (int32 tensor, int32 tensor): where the drawn ids go (instead of ``keep_ids``)."""
         lib = load()
         _dev(indptr, torch.int64, 'indptr', 1)
@@ -771,9 +773,15 @@ class Sage2Call:
                 _dev(out_h0, torch.float32, 'out_h0', 2)
                 if tuple(out_h0.shape) != (self.n_roots, h1):
                     raise ValueError("out_h0 must be (%d, %d)" % (self.n_roots, h1))
+            hop1_out = subtrees.get('draw_hop1')
+            if hop1_out is not None:
+                _dev(hop1_out, torch.int32, 'draw_hop1')
+                if hop1_out.numel() != self.n_roots:
+                    raise ValueError("draw_hop1 must have %d entries" % self.n_roots)
             self._sub = _lib.Sage2Subtrees(r, int(subtrees.get('tape_len', 0)), int(subtrees.get('tape_off_hop2', 0)),
-                                           int(subtrees.get('tape_off_hop3', 0)), ptr(out_h0))
-            self._sub_keep = out_h0
+                                           int(subtrees.get('tape_off_hop3', 0)), ptr(out_h0), None, ptr(hop1_out))
+            self._sub_keep = (out_h0, hop1_out)
+            self._draw_hop1 = hop1_out is not None
         self.emb = emb if emb is not None else torch.empty((self.n_roots, h2), dtype=torch.float32, device=dev)
         _dev(self.emb, torch.float32, 'emb', 2)
         if tuple(self.emb.shape) != (self.n_roots, h2):
@@ -840,8 +848,9 @@ class Sage2Call:
             self._read_weight_addresses()
         _dev(seeds, torch.int32, 'seeds', 1)
         _dev(err_flag, torch.int32, 'err_flag', 1)
-        if seeds.numel() != self.n_roots:
-            raise ValueError("seeds must hold %d roots" % self.n_roots)
+        draw_hop1 = self._sub is not None and self._draw_hop1
+        if seeds.numel() != (2 * self.n_pairs if draw_hop1 else self.n_roots):
+            raise ValueError("seeds must hold %d roots" % (2 * self.n_pairs if draw_hop1 else self.n_roots))
         if walk_ids is not None:
             _dev(walk_ids, torch.int64, 'walk_ids', 1)
             if walk_ids.numel() != 2 * self.n_pairs:
@@ -852,7 +861,8 @@ class Sage2Call:
             if replay.numel() != words:
                 raise ValueError("replay tape has the wrong length")
         if self._sub is not None:
-            check(self._lib.gs_sage2_forward_subtrees(*self._fixed_a, ptr(seeds), self.n_pairs, self._n0, self._n1,
+            self._sub.seeds = ptr(seeds) if draw_hop1 else None
+            check(self._lib.gs_sage2_forward_subtrees(*self._fixed_a, None if draw_hop1 else ptr(seeds), self.n_pairs, self._n0, self._n1,
                                                       int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(walk_id_base) & 0xFFFFFFFFFFFFFFFF,
                                                       ptr(walk_ids), ptr(replay), *self._fixed_b[:6], ptr(self.emb),
                                                       ptr(self.hop1), ptr(self.hop2), ctypes.byref(self._sub),
@@ -865,6 +875,73 @@ class Sage2Call:
                                          ctypes.byref(self._saved) if self._saved is not None else None,
                                          ptr(err_flag), stream_handle()),
               'gs_sage2_forward')
+        return self.emb
+
+
+def sage3_seeds_supported(fu, fi, h1, h2, h3, n0):
+    return bool(load().gs_sage3_seeds_supported(int(fu), int(fi), int(h1), int(h2), int(h3), int(n0)))
+
+
+class Sage3SeedsCall:
+    """A prepared ``gs_sage3_seeds_forward`` call: layers 0, 1, 2 at the seed nodes of a three-hop
+    model on the hop-1 nodes' rows that ``Sage2Call(subtrees=...)`` left.
+
+    ``weights`` = {(layer, node_type): (w_self, w_neigh, bias or None)} for layers 0, 1, 2.
+    """
+
+    def __init__(self, feat_user, feat_item, hop1_ids, n0, h0_hop1, h1_hop1, weights, act, normalize, n_pairs, emb):
+        lib = load()
+        _dev(feat_user, torch.float32, 'feat_user', 2)
+        _dev(feat_item, torch.float32, 'feat_item', 2)
+        _dev(hop1_ids, torch.int32, 'hop1_ids')
+        _dev(h0_hop1, torch.float32, 'h0_hop1', 2)
+        _dev(h1_hop1, torch.float32, 'h1_hop1', 2)
+        _dev(emb, torch.float32, 'emb', 2)
+        (nu, fu), (ni, fi) = feat_user.shape, feat_item.shape
+        n0, n_pairs = int(n0), int(n_pairs)
+        self._w, self._weights, self._epoch = [], weights, _storage_epoch
+        widths = []
+        for layer in (0, 1, 2):
+            for t in ('user', 'item'):
+                w_self, w_neigh, bias = weights[(layer, t)]
+                _dev(w_self, torch.float32, 'w_self', 2)
+                _dev(w_neigh, torch.float32, 'w_neigh', 2)
+                if bias is not None:
+                    _dev(bias, torch.float32, 'bias', 1)
+                self._w.append(_lib.SageWeights(ptr(w_self), ptr(w_neigh), ptr(bias)))
+            widths.append(2 * weights[(layer, 'user')][0].shape[1])
+        h1, h2, h3 = widths
+        want = {(0, 'user'): (fu, fi, h1), (0, 'item'): (fi, fu, h1), (1, 'user'): (h1, h1, h2), (1, 'item'): (h1, h1, h2),
+                (2, 'user'): (h2, h2, h3), (2, 'item'): (h2, h2, h3)}
+        got = {k: (w[0].shape[0], w[1].shape[0], 2 * w[0].shape[1]) for k, w in weights.items()}
+        if got != want:
+            raise ValueError("weight shapes %s do not fit the model %s" % (got, want))
+        if not lib.gs_sage3_seeds_supported(fu, fi, h1, h2, h3, n0):
+            raise _lib.GsageError("the seeds kernel does not cover Fu=%d Fi=%d H=[%d,%d,%d] fan-out %d" % (fu, fi, h1, h2, h3, n0))
+        rows = 2 * n_pairs * n0
+        if hop1_ids.numel() != rows or tuple(h0_hop1.shape) != (rows, h1) or tuple(h1_hop1.shape) != (rows, h2):
+            raise ValueError("hop1_ids / h0_hop1 / h1_hop1 must have %d rows (widths %d, %d)" % (rows, h1, h2))
+        if tuple(emb.shape) != (2 * n_pairs, h3):
+            raise ValueError("emb must be (%d, %d)" % (2 * n_pairs, h3))
+        self.n_pairs, self.emb, self._lib = n_pairs, emb, lib
+        self._keep = [feat_user, feat_item, hop1_ids, h0_hop1, h1_hop1]
+        self._head = (ptr(feat_user), nu, fu, ptr(feat_item), ni, fi)
+        self._tail = (n_pairs, ptr(hop1_ids), n0, ptr(h0_hop1), ptr(h1_hop1), *[ctypes.byref(w) for w in self._w],
+                      h1, h2, h3, ACT[act], int(bool(normalize)), ptr(emb))
+
+    def run(self, seeds):
+        if self._epoch != _storage_epoch:
+            i = 0
+            for layer in (0, 1, 2):
+                for t in ('user', 'item'):
+                    w_self, w_neigh, bias = self._weights[(layer, t)]
+                    self._w[i].w_self, self._w[i].w_neigh, self._w[i].bias = ptr(w_self), ptr(w_neigh), ptr(bias)
+                    i += 1
+            self._epoch = _storage_epoch
+        _dev(seeds, torch.int32, 'seeds', 1)
+        if seeds.numel() != 2 * self.n_pairs:
+            raise ValueError("seeds must hold %d nodes" % (2 * self.n_pairs))
+        check(self._lib.gs_sage3_seeds_forward(*self._head, ptr(seeds), *self._tail, stream_handle()), 'gs_sage3_seeds_forward')
         return self.emb
 
 

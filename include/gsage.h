@@ -444,8 +444,9 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
  * The same kernel below the first hop of a THREE-hop model (models.py:127-190 with three layers;
  * sampler.py:65-90 to depth 3): every hop-1 node v of every walk is the root of a two-hop subtree -- v, its
  * n1 sampled neighbors, their n2 sampled neighbors each -- and everything layer 1 of v depends on is
- * private to that subtree.  One wavefront per subtree draws hops 2 and 3, gathers the subtree's
- * 1 + n1 + n1*n2 feature rows, and leaves
+ * private to that subtree.  A wavefront takes eight consecutive subtrees at a time (their hop-2 nodes as one
+ * list of heads, so that the chain of dependent reads is paid once per eight), draws hops 2 and 3, gathers
+ * each subtree's 1 + n1 + n1*n2 feature rows, and leaves
  *   h1_out[i, :]  = relu(layer 1 at v)     the row layer 2 reads as a neighbor's          [roots, H2]
  *   out_h0[i, :]  = relu(layer 0 at v)     the row layer 1 of the walk's root reads       [roots, H1]
  * so that neither the ids of hops 2 and 3 nor the layer-0 outputs of the hop-2 nodes pass through memory,
@@ -453,20 +454,29 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
  *   hop1_ids   [2*n_pairs * roots_per_walk] the hop-1 nodes as gs_sample writes them (fanouts[0] =
  *              roots_per_walk): those of the user-rooted walks (items) first; root i belongs to seed walk
  *              i / roots_per_walk.  An id of -1 (below an isolated root) gives rows of zeros' images.
+ *              May be NULL when sub->seeds is given.
  *   walk_ids   per SEED walk [2*n_pairs] (or NULL: walk_id_base + seed walk), rng_seed, replay: as gs_sample;
  *              the draws are exactly those of gs_sample over three hops (counter hop = 1 and 2, slot =
  *              the node's slot in the walk); the tape holds tape_len words per seed walk, hop 2 from word
  *              tape_off_hop2 on, hop 3 from tape_off_hop3 on
  *   n1, n2     fan-outs of hops 2 and 3;  l0_* / l1_*: the weights of layers 0 and 1
  *   out_hop2 / out_hop3 (nullable) receive the drawn ids in gs_sample's layout
- * What remains for the caller are the seed roots themselves: layer 0 and layer 1 at the roots (neighbors: the
- * hop-1 nodes' feature rows / out_h0 rows) and layer 2 (neighbors: h1_out rows), e.g. through gs_sage_fused_fwd.
+ *   sub->seeds (nullable) [2*n_pairs] the seed nodes, user seeds first.  Then hop 1 is drawn here as well
+ *              (counter hop 0, slot = the root's position below its seed, tape words [0, roots_per_walk) of
+ *              the seed walk; err_flag as gs_sample for isolated and out-of-range seeds), one group ahead of
+ *              the group being gathered, and written to sub->out_hop1 [2*n_pairs * roots_per_walk]: no
+ *              sampler launch is left.
+ * What remains for the caller are the seed nodes themselves: layer 0 and layer 1 at the seeds (neighbors: the
+ * hop-1 nodes' feature rows / out_h0 rows) and layer 2 (neighbors: h1_out rows): gs_sage3_seeds_forward, or
+ * gs_sage_fused_fwd per layer.
  * Shapes: gs_sage2_supported(Fu, Fi, H1, H2, n1, n2).
  */
 typedef struct gs_sage2_subtrees {
     int32_t roots_per_walk;
     int64_t tape_len, tape_off_hop2, tape_off_hop3;
     float *out_h0;
+    const int32_t *seeds;
+    int32_t *out_hop1;
 } gs_sage2_subtrees;
 
 int gs_sage2_forward_subtrees(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
@@ -480,6 +490,28 @@ int gs_sage2_forward_subtrees(const int64_t *indptr, const int32_t *indices, int
                               int H1, int H2,
                               float *h1_out, int32_t *out_hop2, int32_t *out_hop3,
                               const gs_sage2_subtrees *sub, int32_t *err_flag, void *stream);
+
+/*
+ * Layers 0, 1 and 2 at the seed nodes of a three-hop model, both node types in one launch, on what
+ * gs_sage2_forward_subtrees left (models.py:146-190; l2 normalisation utils.py:109-119 as gs_sage_fused_fwd):
+ *   seeds     [2*n_pairs] user seeds, then item seeds;  hop1_ids [2*n_pairs * n0] their sampled neighbors
+ *   h0_hop1   [2*n_pairs * n0, H1]  layer-0 outputs of the hop-1 nodes (out_h0 above)
+ *   h1_hop1   [2*n_pairs * n0, H2]  layer-1 outputs of the hop-1 nodes (h1_out above)
+ *   emb       [2*n_pairs, H3]       act(layer 2), l2-normalised when normalize != 0
+ * Layers 0 and 1 go through relu; act (GS_ACT_*) is layer 2's.  Neighbor means are sums over all n0 slots
+ * divided by n0 (a missing neighbor, id -1, contributes a zero feature row in layer 0 and its stored rows in
+ * layers 1 and 2, as in the layered entry points).  A wavefront takes four seeds through all three layers.
+ * Shapes: gs_sage3_seeds_supported() != 0 (the widths of gs_sage2_supported, H3 = 32 or 64).
+ */
+int gs_sage3_seeds_supported(int Fu, int Fi, int H1, int H2, int H3, int n0);
+int gs_sage3_seeds_forward(const float *feat_user, int64_t n_users, int Fu,
+                           const float *feat_item, int64_t n_items, int Fi,
+                           const int32_t *seeds, int64_t n_pairs, const int32_t *hop1_ids, int n0,
+                           const float *h0_hop1, const float *h1_hop1,
+                           const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                           const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                           const gs_sage_weights *l2_user, const gs_sage_weights *l2_item,
+                           int H1, int H2, int H3, int act, int normalize, float *emb, void *stream);
 
 /*
  * The layer-0 relu masks for gs_sage2_backward_tail / gs_sage2_backward_tail_head (their nullable l0_mask argument), in which case g_h1 leaves as the

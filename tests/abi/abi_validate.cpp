@@ -43,7 +43,7 @@ int main() {
     int64_t *i64 = reinterpret_cast<int64_t *>(arena + 2048);
     float *odd = reinterpret_cast<float *>(arena + 4);           // not 16-byte aligned
 
-    EXPECT(gs_version() >= 3);
+    EXPECT(gs_version() >= 4);
     EXPECT(gs_last_error() != nullptr);
 
     // ---- timers (no event is created here: that needs a device) ----
@@ -249,7 +249,27 @@ int main() {
         REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
         sub.roots_per_walk = 25; sub.out_h0 = odd;
         REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        sub.out_h0 = f;
+        // neither hop-1 ids nor seeds to draw them from; seeds without a place for the drawn ids
+        REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, nullptr, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        sub.seeds = i32;
+        REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, nullptr, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
     }
+
+    // ---- layers 0, 1, 2 at the seeds of a three-hop model ----
+    EXPECT(gs_sage3_seeds_supported(64, 64, 32, 32, 32, 25) == 1);
+    EXPECT(gs_sage3_seeds_supported(64, 64, 32, 32, 48, 25) == 0);
+    EXPECT(gs_sage3_seeds_supported(24, 19, 32, 32, 32, 25) == 0);
+    EXPECT(gs_sage3_seeds_supported(64, 64, 32, 32, 32, 0) == 0);
+    ACCEPTED(gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, i32, 0, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, nullptr));
+    REFUSED(GS_EINVAL, gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, i32, -1, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, nullptr));
+    REFUSED(GS_EINVAL, gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, nullptr, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, nullptr));
+    REFUSED(GS_EINVAL, gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, nullptr, 32, 32, 32, GS_ACT_LINEAR, 1, f, nullptr));
+    REFUSED(GS_EINVAL, gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w_hole, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, nullptr));
+    REFUSED(GS_EINVAL, gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, odd, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, nullptr));
+    REFUSED(GS_EINVAL, gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, 7, 1, f, nullptr));
+    REFUSED(GS_EINVAL, gs_sage3_seeds_forward(f, 0, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, nullptr));
+    REFUSED(GS_ELIMIT, gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 48, GS_ACT_LINEAR, 1, f, nullptr));
 
     // ---- top of the backward pass ----
     ACCEPTED(gs_sage2_backward_tail(f, f, f, f, 0, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));

@@ -621,9 +621,9 @@ def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_
 @pytest.mark.parametrize('ns,sizes,fu,fi,b', [([6, 4, 3], [32, 32, 32], 64, 64, 24), ([25, 10, 5], [32, 32, 32], 64, 64, 40),
                                                 ([3, 5, 2], [64, 64, 32], 64, 64, 130), ([4, 3, 2], [32, 32, 64], 32, 32, 7)])
 def test_three_hop_engine_through_the_subtree_kernel(cuda, ns, sizes, fu, fi, b):
-    """Three hops with everything below the first hop in one kernel (gs_sage2_forward_subtrees): the ids it
-    draws are gs_sample's, with Philox keys and with a replay tape, and the embeddings equal those of the
-    layer-by-layer kernels."""
+    """Three hops in two launches (gs_sage2_forward_subtrees drawing all three hops, gs_sage3_seeds_forward for
+    the seeds): the ids are gs_sample's, with Philox keys and with a replay tape, and the embeddings equal
+    those of the layer-by-layer kernels."""
     from graphsage_amd.engine import SageForwardEngine
     rng = np.random.default_rng(b)
     nu, ni = 400, 90
@@ -642,7 +642,7 @@ def test_three_hop_engine_through_the_subtree_kernel(cuda, ns, sizes, fu, fi, b)
     seeds = torch.tensor(list(e[0, :b]) + list(e[1, :b]), dtype=torch.int32, device=cuda)
     walk_ids = torch.arange(100, 100 + 2 * b, dtype=torch.int64, device=cuda)
     eng_s = SageForwardEngine(g, model, b, keep_ids=True, subtree_kernel=True)
-    eng_g = SageForwardEngine(g, model, b)                             # sampler + one fused kernel per layer and type
+    eng_g = SageForwardEngine(g, model, b, subtree_kernel=False)       # sampler + one fused kernel per layer and type
     assert eng_s.subtree_kernel and not eng_g.subtree_kernel
     tape = torch.from_numpy(rng.integers(0, 2 ** 32, 2 * b * sum(eng_s.sizes[1:]), dtype=np.uint64).astype(np.uint32)
                             .view(np.int32)).to(cuda)
@@ -659,6 +659,65 @@ def test_three_hop_engine_through_the_subtree_kernel(cuda, ns, sizes, fu, fi, b)
     eng_s.forward(seeds, walk_ids, rng_seed=77)
     for a, c in zip(eng_s.hops, want):
         np.testing.assert_array_equal(a.cpu().numpy().astype(np.int64), c)
+
+
+def test_subtree_route_with_isolated_and_invalid_seeds(cuda):
+    """Seeds without neighbors and seeds outside the graph through the two-launch three-hop route: the same -1
+    ids, error flags and embeddings as the sampler + layer kernels; hop-1 ids handed in give the same rows as
+    hop-1 ids drawn by the kernel."""
+    from graphsage_amd.engine import SageForwardEngine
+    from graphsage_amd import kernels
+    rng = np.random.default_rng(3)
+    nu, ni, b = 120, 50, 11
+    u = rng.integers(5, nu, 900)                                   # users 0..4 have no edges
+    it = rng.integers(0, ni - 3, 900) + nu                         # the last three items neither
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, 64)).astype(np.float32),
+             'item': rng.standard_normal((ni, 64)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    ns = [5, 4, 3]
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=4)
+    model = ga.GraphSAGE([32, 32, 32], gen, seed=6).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.1, 0.1)
+    su = [0, 3] + list(e[0, :b - 2])
+    si = [nu + ni - 1] + list(e[1, :b - 1])
+    seeds = torch.tensor(su + si, dtype=torch.int32, device=cuda)
+    eng_s = SageForwardEngine(g, model, b, keep_ids=True, subtree_kernel=True)
+    eng_g = SageForwardEngine(g, model, b, subtree_kernel=False)
+    assert eng_s.subtree_kernel and not eng_g.subtree_kernel
+    out_s = [x.clone() for x in eng_s.forward(seeds, None, rng_seed=9)]
+    out_g = [x.clone() for x in eng_g.forward(seeds, None, rng_seed=9)]
+    assert eng_s.err_flag.tolist() == eng_g.err_flag.tolist() == [nu + ni, 0]
+    for a, c in zip(eng_s.hops, eng_g.hops):
+        assert torch.equal(a, c)
+    assert (eng_s.hops[0][0] == -1).all() and (eng_s.hops[2][b] == -1).all()
+    for a, c in zip(out_s, out_g):
+        close(a, c.double(), scale=float(c.abs().max()))
+    # a seed outside the graph
+    bad = seeds.clone()
+    bad[4] = nu + ni + 7
+    for eng in (eng_s, eng_g):
+        eng.err_flag.zero_()
+        eng.forward(bad, None, rng_seed=9)
+    assert eng_s.err_flag.tolist()[1] == eng_g.err_flag.tolist()[1] == 1
+    assert torch.equal(eng_s.hops[0], eng_g.hops[0]) and (eng_s.hops[0][4] == -1).all()
+    # hop-1 ids handed in: the same rows, bit for bit
+    st = eng_s._subtree
+    eng_s.forward(seeds, None, rng_seed=9)
+    h0, h1 = st['h0'].clone(), st['h1'].clone()
+    m = model
+    weights = {(l, t): (m._aggs[l][t].w_self, m._aggs[l][t].w_neigh, m._aggs[l][t].bias) for l in (0, 1) for t in ('user', 'item')}
+    out_h0 = torch.empty_like(h0)
+    call = kernels.Sage2Call(eng_s.indptr, eng_s.indices, eng_s.tables['user'][0], eng_s.tables['item'][0], ns[1:], weights,
+                             False, b, subtrees={'roots_per_walk': ns[0], 'tape_len': sum(eng_s.sizes[1:]),
+                                                 'tape_off_hop2': eng_s.sizes[1], 'tape_off_hop3': eng_s.sizes[1] + eng_s.sizes[2],
+                                                 'out_h0': out_h0})
+    err = torch.zeros(2, dtype=torch.int32, device=cuda)
+    got = call.run(eng_s.hops[0].reshape(-1), err, rng_seed=9)
+    assert torch.equal(got, h1) and torch.equal(out_h0, h0)
 
 
 def test_engine_wide_kernel_on_every_layer_matches_general_kernels(cuda):
