@@ -519,6 +519,55 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     }
 }
 
+// Neighbor means of a tile of up to 16 heads into A: KH heads per lane group and iteration, up to KU children
+// each, their row loads all issued before the first add (what keeps enough bytes in flight per wave).
+template <int FT, int LDA, bool BUF, int KH, int KU>
+__device__ __forceinline__ void tile_means(const RowTable<BUF> &tabT, const int32_t *hop2, int j0, int np, int n1,
+                                           int lane, float *A) {
+    constexpr int FTV = FT / 4, GN_T = 64 / FTV;
+    static_assert(KH * GN_T <= 16, "more heads per iteration than a tile has");
+    const int g = lane / FTV, c = lane % FTV;
+    const unsigned col = (unsigned)c * 16u;
+    const float denom = (float)n1;
+    const int rounds = (n1 + KU - 1) / KU;
+    const int per = (n1 + rounds - 1) / rounds;
+    for (int pp0 = g; pp0 < 16; pp0 += KH * GN_T) {
+        float4 acc[KH];
+#pragma unroll
+        for (int hd = 0; hd < KH; ++hd) acc[hd] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = 0; c0 < n1; c0 += per) {
+            float4 v[KH][KU];
+#pragma unroll
+            for (int hd = 0; hd < KH; ++hd) {
+                const int pp = pp0 + hd * GN_T;
+                const int32_t *ids = hop2 + (j0 + min(pp, np - 1)) * n1;
+                int32_t cid[KU];                          // all id reads first: one LDS wait per batch
+#pragma unroll
+                for (int u = 0; u < KU; ++u) cid[u] = ids[min(c0 + u, n1 - 1)];
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    const bool want = (pp < np) && (u < per) && (c0 + u < n1);
+                    v[hd][u] = tabT.load_entry(want, cid[u], col, FT * 4);
+                }
+            }
+#pragma unroll
+            for (int hd = 0; hd < KH; ++hd)
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    acc[hd].x += v[hd][u].x; acc[hd].y += v[hd][u].y;
+                    acc[hd].z += v[hd][u].z; acc[hd].w += v[hd][u].w;
+                }
+        }
+#pragma unroll
+        for (int hd = 0; hd < KH; ++hd) {
+            const int pp = pp0 + hd * GN_T;
+            if (pp < 16)
+                *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) =
+                    make_float4(acc[hd].x / denom, acc[hd].y / denom, acc[hd].z / denom, acc[hd].w / denom);
+        }
+    }
+}
+
 // Subtree mode, G roots per wavefront.  A subtree of fan-outs [10, 5] is 61 rows behind the same chain of
 // dependent reads as a whole walk; taking G subtrees through that chain together -- their hop-1 heads as ONE
 // list of G * n0 heads, the G roots as G rows of one tile -- amortises it the way a walk of fan-outs [25, 10]
@@ -638,8 +687,6 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
     for (int k = 0; k < L1_N; ++k) hs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int RP_O = 64 / FOV, NPASS_O = 16 / RP_O;     // own rows per load instruction / passes per tile
     constexpr int GN_T = 64 / FTV;                           // lane groups summing children rows
-    const int rounds = (n1 + kUnroll - 1) / kUnroll;
-    const int per = (n1 + rounds - 1) / rounds;
     for (int j0 = 0; j0 < NH; j0 += 16) {
         const int np = min(16, NH - j0);
         float4 own[NPASS_O];
@@ -649,50 +696,12 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
             const int32_t id = hop1[j0 + min(rr, np - 1)];
             own[pass] = tabO.load(rr < np, (unsigned)(id - offO), (unsigned)c * 16u, FO * 4);
         }
-        {
-            // kHeads heads per lane group and iteration: their row loads are all issued before
-            // the first add, which is what keeps enough bytes in flight per wave
-            const int g = lane / FTV, c = lane % FTV;
-            const unsigned col = (unsigned)c * 16u;
-            const float denom = (float)n1;
-            constexpr int kHeads = heads_in_flight(HH1);
-            for (int pp0 = g; pp0 < 16; pp0 += kHeads * GN_T) {
-                float4 acc[kHeads];
-#pragma unroll
-                for (int hd = 0; hd < kHeads; ++hd) acc[hd] = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int c0 = 0; c0 < n1; c0 += per) {
-                    float4 v[kHeads][kUnroll];
-#pragma unroll
-                    for (int hd = 0; hd < kHeads; ++hd) {
-                        const int pp = pp0 + hd * GN_T;
-                        const int32_t *ids = hop2 + (j0 + min(pp, np - 1)) * n1;
-                        int32_t cid[kUnroll];                 // all id reads first: one LDS wait per batch
-#pragma unroll
-                        for (int u = 0; u < kUnroll; ++u) cid[u] = ids[min(c0 + u, n1 - 1)];
-#pragma unroll
-                        for (int u = 0; u < kUnroll; ++u) {
-                            const bool want = (pp < np) && (u < per) && (c0 + u < n1);
-                            v[hd][u] = tabT.load_entry(want, cid[u], col, FT * 4);
-                        }
-                    }
-#pragma unroll
-                    for (int hd = 0; hd < kHeads; ++hd)
-#pragma unroll
-                        for (int u = 0; u < kUnroll; ++u) {
-                            acc[hd].x += v[hd][u].x; acc[hd].y += v[hd][u].y;
-                            acc[hd].z += v[hd][u].z; acc[hd].w += v[hd][u].w;
-                        }
-                }
-#pragma unroll
-                for (int hd = 0; hd < kHeads; ++hd) {
-                    const int pp = pp0 + hd * GN_T;
-                    if (pp < 16) {
-                        const float4 mean = make_float4(acc[hd].x / denom, acc[hd].y / denom, acc[hd].z / denom, acc[hd].w / denom);
-                        *reinterpret_cast<float4 *>(A + pp * LDA + 4 * c) = mean;
-                    }
-                }
-            }
-        }
+        // short child lists (at most kUnroll / 2 per head): twice the heads per iteration instead, the same
+        // number of row loads in flight per lane
+        constexpr int KH = heads_in_flight(HH1);
+        constexpr bool kShort = 2 * KH * GN_T <= 16;      // (a tile has the heads for it)
+        if (kShort && 2 * n1 <= kUnroll) tile_means<FT, LDA, BUF, kShort ? 2 * KH : KH, kUnroll / 2>(tabT, hop2, j0, np, n1, lane, A);
+        else tile_means<FT, LDA, BUF, KH, kUnroll>(tabT, hop2, j0, np, n1, lane, A);
         wave_lds_fence();
         if (SAVE) {                          // the tile of neighbor means, out of LDS: np consecutive table rows
             float *dst = a.sv_x_mean[1 - side] + (size_t)(sv_h1row + j0) * FT;
