@@ -552,18 +552,11 @@ class SageForwardEngine:
 
     # algorithmic bytes of one step, per the accounting used for the roofline
     def algorithmic_bytes(self):
-        """(sampler bytes, gather+aggregate bytes) one batch must move at least on the route this engine takes.
-        Layered routes: ids and CSR row bounds read, sampled ids written; every sampled node's feature row read
+        """(sampler bytes, gather+aggregate bytes) of one batch by the layered accounting, whatever route the
+        engine takes: ids and CSR row bounds read, sampled ids written; every sampled node's feature row read
         once and the layer-0 inputs (own row + neighbor mean per head node) written once.  The one- and
-        two-launch routes write neither ids nor layer inputs: their kernels' own accounting."""
-        if self.walk_kernel:
-            return 0, self.dominant_bytes()
-        if self.subtree_kernel:
-            b, f, d = self.batch, self.graph.node_feature_sizes, self.model.dims
-            n0 = self.fanouts[0]
-            seeds = sum(4 + 4 * n0 + 4 * f[t] + 4 * n0 * f[self.other[t]] + 4 * n0 * (d[1][t] + d[2][t]) + 4 * d[3][t]
-                        for t in _TYPES)
-            return 0, self.dominant_bytes() + b * seeds
+        two-launch routes move less (no id round trip, no layer inputs written): ``dominant_bytes`` is their own
+        accounting, and the one the roofline figure uses."""
         return self._layered_bytes()
 
     def _layered_bytes(self):

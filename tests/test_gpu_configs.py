@@ -8,7 +8,10 @@ and seeds, taken from ``bench.WORKLOADS``):
 * cfg4: 100 M users x 10 M items, 2 B edges (4e9 CSR entries: row starts beyond
   2**32, feature tables beyond 4 GiB);
 * cfg5: the 1 M x 100 k graph with 256-wide features, three hops [25, 10, 5] and
-  256 hidden units (the wide-layer kernel).
+  256 hidden units (the wide-layer kernel);
+* cfg2h3: the same graph with the default workload's 64-wide features and 32
+  hidden units, three hops [25, 10, 5] (the two-launch route: everything below
+  the seeds in one kernel, then the seeds' three layers).
 
 Checks per workload, as for the default workload in test_gpu_fullsize.py: every
 walk of a full batch bit-exact against the numpy oracle walk on the same Philox
@@ -36,7 +39,8 @@ pytestmark = pytest.mark.gpu
 
 SEED = 0x9E3779B97F4A7C15
 # seed edges per batch as bench.py runs each workload; device memory the graph build needs
-CASES = {'cfg3': dict(batch=4096, gib=40), 'cfg4': dict(batch=4096, gib=150), 'cfg5': dict(batch=1024, gib=20)}
+CASES = {'cfg2h3': dict(batch=4096, gib=20), 'cfg3': dict(batch=4096, gib=40), 'cfg4': dict(batch=4096, gib=150),
+         'cfg5': dict(batch=1024, gib=20)}
 
 
 class _DeviceIndices:
@@ -166,6 +170,11 @@ def test_forward_main_route_equals_general_kernels_and_oracle_subset(load):
         assert eng.walk_kernel                                     # ONE kernel: sample + both layers
         lay = SageForwardEngine(g, model, b, walk_kernel=False)
         assert all(lay.fused_layers)
+    elif load['name'] == 'cfg2h3':
+        assert eng.subtree_kernel                                  # TWO launches, no sampler launch
+        eng = SageForwardEngine(g, model, b, keep_ids=True)
+        lay = SageForwardEngine(g, model, b, subtree_kernel=False)
+        assert all(lay.fused_layers) and not lay.subtree_kernel
     else:
         assert eng.wide_first_layer_only and all(eng.fused_layers)  # sampler + wide layer 0 + general tail
         lay = None
@@ -180,6 +189,9 @@ def test_forward_main_route_equals_general_kernels_and_oracle_subset(load):
         out_lay = [x.clone() for x in lay.forward(seeds, walk_ids, rng_seed=SEED)]
         for k in range(2):
             _close(out[k], out_lay[k], "one kernel vs one kernel per layer [%d]" % k)
+    if eng.subtree_kernel:                                         # the ids its kernel drew are the sampler's
+        for a, c in zip(eng.hops, alt.hops):
+            assert torch.equal(a, c)
 
     # float64 oracle on the first links of the batch, from the ids the general route sampled;
     # rows fetched with torch indexing (not this library's gathers)

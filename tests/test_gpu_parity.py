@@ -619,7 +619,9 @@ def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_
 
 
 @pytest.mark.parametrize('ns,sizes,fu,fi,b', [([6, 4, 3], [32, 32, 32], 64, 64, 24), ([25, 10, 5], [32, 32, 32], 64, 64, 40),
-                                                ([3, 5, 2], [64, 64, 32], 64, 64, 130), ([4, 3, 2], [32, 32, 64], 32, 32, 7)])
+                                                ([3, 5, 2], [64, 64, 32], 64, 64, 130), ([4, 3, 2], [32, 32, 64], 32, 32, 7),
+                                                ([5, 7, 4], [32, 32, 32], 128, 128, 33), ([9, 2, 6], [32, 32, 32], 64, 32, 21),
+                                                ([2, 11, 1], [32, 32, 64], 32, 64, 50), ([30, 1, 12], [32, 32, 32], 64, 64, 3)])
 def test_three_hop_engine_through_the_subtree_kernel(cuda, ns, sizes, fu, fi, b):
     """Three hops in two launches (gs_sage2_forward_subtrees drawing all three hops, gs_sage3_seeds_forward for
     the seeds): the ids are gs_sample's, with Philox keys and with a replay tape, and the embeddings equal

@@ -34,7 +34,7 @@ ours = ('sage2_kernel', 'sage3_seeds_kernel', 'sage2_tail_bwd_kernel', 'stage_ba
 
 WIDE_READERS = ('sage2_kernel', 'sage3_seeds_kernel', 'sage_fused_kernel', 'sage_wide_kernel', 'gather_mean_kernel', 'gather_rows_kernel',
                 'rows_gemm', 'wgrad', 'sage2_tail_bwd_kernel', 'link_head', 'adam_kernel', 'l2norm')
-SOURCE_OF = {'sage2_kernel': 'sage2.hip', 'sage_fused_kernel': 'fused.hip', 'sage_wide_kernel': 'wide.hip',
+SOURCE_OF = {'sage2_kernel': ('sage2.hip', 'sage_tile.h'), 'sage3_seeds_kernel': ('sage3_seeds.hip', 'sage_tile.h'), 'sage_fused_kernel': 'fused.hip', 'sage_wide_kernel': 'wide.hip',
              'sample_kernel': 'sampler.hip', 'gather_mean_kernel': 'gather.hip'}
 
 
@@ -160,10 +160,11 @@ if len(sys.argv) >= 6:
         base = k.split('<')[0]
         if base not in SOURCE_OF or 'fetch' not in d:
             continue
-        src_file = os.path.join('graphsage_amd', 'csrc', SOURCE_OF[base])
+        names = SOURCE_OF[base] if isinstance(SOURCE_OF[base], tuple) else (SOURCE_OF[base],)
+        src_files = [os.path.join('graphsage_amd', 'csrc', n) for n in names]
         key = '%s/%s/B%d/%s' % (workload, k, batch, fan)        # k keeps the template arguments: variants stay apart
         rec[key] = {'bytes': fetch_factor(k) * d['fetch'][0] + d.get('write', (0.0, 0))[0],
                     'fetch_raw': d['fetch'][0], 'fetch_factor': fetch_factor(k), 'write': d.get('write', (0.0, 0))[0],
-                    'launches': d['fetch'][1], 'source': {src_file: blob_hash(os.path.join(root, src_file))},
+                    'launches': d['fetch'][1], 'source': {f: blob_hash(os.path.join(root, f)) for f in src_files},
                     'profile': 'profiles/%s.md' % name}
     json.dump(rec, open(tj, 'w'), indent=1, sort_keys=True)
