@@ -159,9 +159,10 @@ def cpu_baseline(graph, cfg, heads_u, heads_i, model, n_batches, batch=100):
         return time.perf_counter() - t0
 
     # bounded sample: as many batches as fit in about 12 s (wide or deep workloads take seconds per batch)
-    t_first = one_pass(1)
-    n_batches = max(2, min(n_batches, int(12.0 / max(t_first, 1e-3))))
-    print("[bench] cpu baseline: %.2f s for the first batch, timing %d batches" % (t_first, n_batches),
+    t_first = one_pass(1)            # cold: builds the neighbor lists it touches
+    t_warm = one_pass(1)
+    n_batches = max(2, min(n_batches, int(12.0 / max(t_warm, 1e-3))))
+    print("[bench] cpu baseline: %.2f s for the first batch (%.2f s warm), timing %d batches" % (t_first, t_warm, n_batches),
           file=sys.stderr, flush=True)
     one_pass(n_batches)              # fills the neighbor-list cache (the reference holds plain lists)
     dt = one_pass(n_batches)
