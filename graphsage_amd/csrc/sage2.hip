@@ -45,6 +45,9 @@ constexpr int heads_in_flight(int hh1) { return hh1 >= 32 ? 2 : 1; }
 // registers, and the spill traffic costs more than the four extra waves hide (588 against 528 us per launch on
 // three hops at 64-wide features, fan-outs [25, 10, 5]).
 constexpr int sub_waves(int hh1) { return hh1 >= 32 ? 8 : 12; }
+// The saving form (training) likewise: 31 spilled vector registers at sixteen waves, none at twelve (training step
+// 194 -> 189 us on the default workload); the plain walk kernel has none at sixteen and is faster there.
+constexpr int block_waves(int hh1, bool save, bool sub) { return (save || sub) ? sub_waves(hh1) : max_waves(hh1); }
 constexpr int kUnroll = 10;              // row loads in flight per lane in the mean phase
 constexpr int kChunks = 4;               // 64-slot chunks sampled per pass
 constexpr int kGroup = 8;                // subtree mode: roots a wavefront takes together
@@ -746,7 +749,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
 }
 
 template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB>
-__global__ __launch_bounds__((SUB ? sub_waves(HH1) : max_waves(HH1)) * 64)
+__global__ __launch_bounds__(block_waves(HH1, SAVE, SUB) * 64)
 void sage2_kernel(const Sage2Args a) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     constexpr int H1 = S::H1, H2 = S::H2, LDA = S::LDA, LDH = S::LDH;
@@ -874,7 +877,7 @@ template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB = fals
 int launch_one(const Sage2Args &a, hipStream_t stream) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     constexpr int roots = SUB ? kGroup : 0;
-    int waves = SUB ? sub_waves(HH1) : max_waves(HH1);                          // as many waves per CU as the LDS budget admits
+    int waves = block_waves(HH1, SAVE, SUB);                          // as many waves per CU as the LDS budget admits
     while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves, roots) > kLdsMax) waves -= 2;
     const size_t lds = S::lds_bytes(a.n0, a.n1, waves, roots);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
