@@ -23,6 +23,7 @@ BENCH_EAGER_TRAIN=1 launches the training step kernel by kernel instead of
 replaying a captured HIP graph; BENCH_WATCHDOG_S bounds the whole run.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -359,21 +360,40 @@ def main():
         k = my_batches[i % len(my_batches)]
         return engine.forward(seeds[k], walk_ids[k], rng_seed=gen.sampler.seed)
 
+    # warm-up covers every path of the timed loop, the event-carrying launch included: its first use creates
+    # HIP events and pages code in (tens of milliseconds on a fresh machine), which belongs here
+    scratch_probes = []
     for i in range(args.warmup):
+        engine.probes = scratch_probes if i % 5 == 0 else None
         step(i)
+    engine.probes = None
     torch.cuda.synchronize()
+    for t in scratch_probes:
+        t.elapsed_us()
     # the dominant kernel of every fifth step of the timed region is launched with a pair of HIP
     # events in its own dispatch packet (exact start/end of that kernel on its stream)
     probes = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # The collector stays out of the timed loops, as timeit keeps it: a full collection over the heap the graph
+    # build leaves behind takes tens of milliseconds, and in a process that has just compiled its modules it fell
+    # on the first timed step (0.9 ms per step reported for a 0.1 ms step).
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
+    stamps = [] if os.environ.get('BENCH_STEP_TIMES') else None     # host time after each step's launches (debugging aid)
     for i in range(args.steps):
         engine.probes = probes if i % 5 == 0 else None
         step(args.warmup + i)
+        if stamps is not None:
+            stamps.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0                       # this rank's K steps; the slowest rank counts (MAX below)
+    gc.enable()
+    if stamps is not None:
+        print("[bench] host ms after each step: %s; after the final synchronize: %.3f"
+              % (' '.join('%.3f' % (1e3 * x) for x in stamps), 1e3 * elapsed), file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     engine.probes = None
@@ -445,11 +465,14 @@ def main():
                 warm_up()
             if world > 1:
                 dist.barrier()
+            gc.collect()
+            gc.disable()
             t1 = time.perf_counter()
             for i in range(args.train_steps):
                 tstep(5 + i)
             torch.cuda.synchronize()
             t_el = time.perf_counter() - t1
+            gc.enable()
             if world > 1:
                 dist.barrier()
             if world > 1:
