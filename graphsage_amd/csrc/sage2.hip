@@ -104,7 +104,7 @@ struct Sage2Shape {
 };
 
 // One walk.  FT / FO: feature widths of the root's type and of the other type.
-template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, bool SAVE, bool SUB>
+template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, bool SAVE>
 __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int side, int lane,
                                           int32_t root, int64_t ra, int64_t rb,
                                           int32_t next_root, int64_t &next_ra, int64_t &next_rb,
@@ -125,26 +125,20 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     asm volatile("" : "+v"(wl));            // keeps the weight-fragment reads inside the walk loop
 
     // ---- sampling ---------------------------------------------------------------
-    // the caller maps out-of-range roots to -1, or to -2 where -1 itself is a legitimate entry (subtree roots
-    // below an isolated node, which the sampler has reported)
-    if (root < (SUB ? -1 : 0) && lane == 0) atomicMax(&a.err[1], 1);
-    // seed walk and position below it (whole walks: the walk itself, position 0)
-    const long long seed_walk = SUB ? w / a.sub_n : w;
-    const unsigned sub_j = SUB ? (unsigned)(w - seed_walk * a.sub_n) : 0u;
-    constexpr unsigned hop_base = SUB ? 1u : 0u;
-    const unsigned slot0 = sub_j * (unsigned)n0, slot1 = sub_j * (unsigned)(n0 * n1);
-    const unsigned long long walk = a.walk_ids ? (unsigned long long)a.walk_ids[seed_walk] : a.walk_base + (unsigned long long)seed_walk;
+    // the caller maps out-of-range roots to -1
+    if (root < 0 && lane == 0) atomicMax(&a.err[1], 1);
+    const unsigned long long walk = a.walk_ids ? (unsigned long long)a.walk_ids[w] : a.walk_base + (unsigned long long)w;
     const unsigned wlo = (unsigned)walk, whi = (unsigned)(walk >> 32);
-    const uint32_t *tape = a.replay ? a.replay + (size_t)seed_walk * (SUB ? a.tape_len : (long long)(n0 + n0 * n1)) : nullptr;
-    const uint32_t *tape0 = tape ? tape + (SUB ? a.tape_off0 + slot0 : 0) : nullptr;
-    const uint32_t *tape1 = tape ? tape + (SUB ? a.tape_off1 + slot1 : (long long)n0) : nullptr;
+    const uint32_t *tape = a.replay ? a.replay + (size_t)w * (n0 + n0 * n1) : nullptr;
+    const uint32_t *tape0 = tape;
+    const uint32_t *tape1 = tape ? tape + n0 : nullptr;
     wave_lds_fence();                        // the previous walk's readers of s_ids / A / H1t are done
     {
         const uint32_t deg = (uint32_t)(rb - ra);
         if (root >= 0 && deg == 0 && lane == 0) atomicMax(&a.err[0], root + 1);
         const bool live = root >= 0 && deg != 0;
         for (int t = lane; t < n0; t += 64) {
-            const uint32_t rr = tape ? tape0[t] : gs::philox4x32_10_x(wlo, whi, hop_base, slot0 + (uint32_t)t, a.key0, a.key1);
+            const uint32_t rr = tape ? tape0[t] : gs::philox4x32_10_x(wlo, whi, 0u, (uint32_t)t, a.key0, a.key1);
             int32_t v = a.indices[live ? ra + (int64_t)__umulhi(rr, deg) : 0];
             if (!live) v = -1;
             hop1[t] = v;
@@ -174,7 +168,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
                 const uint32_t deg = (uint32_t)(cb[c] - ca[c]);
                 uint32_t rr = 0;
                 if (tape) { if (t < total) rr = tape1[t]; }
-                else rr = gs::philox4x32_10_x(wlo, whi, hop_base + 1u, slot1 + (uint32_t)t, a.key0, a.key1);
+                else rr = gs::philox4x32_10_x(wlo, whi, 1u, (uint32_t)t, a.key0, a.key1);
                 const bool live = p[c] >= 0 && deg != 0;
                 if (p[c] >= 0 && deg == 0) atomicMax(&a.err[0], p[c] + 1);
                 v[c] = a.indices[live ? ca[c] + (int64_t)__umulhi(rr, deg) : 0];
@@ -397,17 +391,14 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         for (int ct = 0; ct < NT2; ++ct) {
             o[0][ct] = acc_s[ct][0] + b1_T[ct * 16 + r];
             o[1][ct] = acc_n[ct][0] + b1_T[HH2 + ct * 16 + r];
-            if (SUB) { o[0][ct] = fmaxf(o[0][ct], 0.f); o[1][ct] = fmaxf(o[1][ct], 0.f); }   // an inner layer
             ss += o[0][ct] * o[0][ct] + o[1][ct] * o[1][ct];
         }
-        if (SUB && a.out_h0 && lane < H1V)           // the root's layer-0 output (the layer above reads it as a neighbor's)
-            *reinterpret_cast<float4 *>(a.out_h0 + (size_t)w * H1 + 4 * lane) = *reinterpret_cast<const float4 *>(H1t + 4 * lane);
         if (SAVE && q == 0) {
             float *dz = a.sv_z[side] + (size_t)pair * H2;
 #pragma unroll
             for (int ct = 0; ct < NT2; ++ct) { dz[ct * 16 + r] = o[0][ct]; dz[HH2 + ct * 16 + r] = o[1][ct]; }
         }
-        if (!SUB && a.normalize) {
+        if (a.normalize) {
 #pragma unroll
             for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m, 64);
             const float inv = rsqrtf(fmaxf(ss, 1e-12f));
@@ -478,7 +469,8 @@ __device__ __forceinline__ void tile_means(const RowTable<BUF> &tabT, const int3
 // dependent reads as a whole walk; taking G subtrees through that chain together -- their hop-1 heads as ONE
 // list of G * n0 heads, the G roots as G rows of one tile -- amortises it the way a walk of fan-outs [25, 10]
 // does.  Roots are consecutive entries of the hop-1 array (they may belong to different seed walks: walk id
-// and slot offsets are per root).  Same arithmetic as walk_body with SUB; the neighbor sum of a root is taken
+// and slot offsets are per root).  The arithmetic of walk_body one hop down (sampler hops 1 and 2, slots shifted by
+// the root's position below its seed, relu after layer 1, no normalisation); the neighbor sum of a root is taken
 // over its heads in list order.
 template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, int G>
 __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int n_valid, int side, int lane,
@@ -864,10 +856,10 @@ void sage2_kernel(const Sage2Args a) {
         const int32_t next_root = pn < a.n_pairs ? load_root(pn) : -1;
         int64_t nra = 0, nrb = 0;
         if (side == 0)
-            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF, SAVE, SUB>(a, base + p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF, SAVE>(a, base + p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_u, w0n_u, w0s_i, w0n_i, w1s, w1n, bias, bias + H1, bias + 2 * H1);
         else
-            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF, SAVE, SUB>(a, base + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF, SAVE>(a, base + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_i, w0n_i, w0s_u, w0n_u, w1s, w1n, bias + H1, bias, bias + 2 * H1);
         root = next_root; ra = nra; rb = nrb;
     }
