@@ -254,3 +254,53 @@ def test_fused_layer_random_shapes_equal_the_general_kernels(cuda, seed):
     if save:
         assert torch.equal(save_s, torch.cat(want_s))
         assert float((save_m - torch.cat(want_m)).abs().max()) <= 1e-5 * max(1.0, float(torch.cat(want_m).abs().max()))
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_three_hop_two_launch_route_random_shapes(cuda, seed):
+    """Random fan-outs, widths, batch sizes and graphs (some nodes without neighbors) through the two-launch
+    three-hop route (gs_sage2_forward_subtrees + gs_sage3_seeds_forward): ids, error flags and embeddings equal
+    those of the sampler + the general kernels."""
+    import graphsage_amd as ga
+    from graphsage_amd.engine import SageForwardEngine
+    rng = np.random.default_rng(900 + seed)
+    fu, fi = [(64, 64), (32, 32), (128, 128), (64, 32), (32, 64)][int(rng.integers(0, 5))]
+    if (fu, fi) == (64, 64):
+        h1, h2 = [(32, 32), (64, 64), (64, 32), (32, 64)][int(rng.integers(0, 4))]
+    elif fu == fi:
+        h1, h2 = [(32, 32), (64, 64)][int(rng.integers(0, 2))]
+    else:
+        h1, h2 = 32, 32
+    h3 = int(rng.choice([32, 64]))
+    fan = [int(rng.integers(1, 31)), int(rng.integers(1, 13)), int(rng.integers(1, 9))]
+    nu, ni, b = int(rng.integers(30, 400)), int(rng.integers(10, 90)), int(rng.integers(1, 70))
+    ne = int(rng.integers(200, 3000))
+    lone_u, lone_i = int(rng.integers(0, 4)), int(rng.integers(0, 3))        # nodes without neighbors
+    u = rng.integers(lone_u, nu, ne)
+    it = rng.integers(0, ni - lone_i, ne) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, fu)).astype(np.float32),
+             'item': rng.standard_normal((ni, fi)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))}, np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, b, fan, head_node_types=['user', 'item'], seed=seed)
+    model = ga.GraphSAGE([h1, h2, h3], gen, seed=seed + 1).build()
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.2, 0.2)
+    su = rng.integers(0, nu, b)                                    # any user, the lone ones included
+    si = rng.integers(0, ni, b) + nu
+    seeds = torch.tensor(list(su) + list(si), dtype=torch.int32, device=cuda)
+    walk_ids = torch.from_numpy(rng.integers(0, 2 ** 40, 2 * b)).to(cuda)
+    eng = SageForwardEngine(g, model, b, keep_ids=True)
+    ref = SageForwardEngine(g, model, b, use_fused=False)
+    if not eng.subtree_kernel:
+        pytest.skip("shape outside the two-launch route: fan-outs %s widths %s" % (fan, (fu, fi, h1, h2, h3)))
+    out = [x.clone() for x in eng.forward(seeds, walk_ids, rng_seed=seed + 5)]
+    want = [x.clone() for x in ref.forward(seeds, walk_ids, rng_seed=seed + 5)]
+    assert eng.err_flag.tolist() == ref.err_flag.tolist()
+    for a, c in zip(eng.hops, ref.hops):
+        assert torch.equal(a, c), (fan, fu, fi)
+    for k in range(2):
+        d = (out[k].double() - want[k].double()).abs()
+        tol = 1e-5 * want[k].double().abs() + 1e-6 * float(want[k].abs().max())
+        assert bool((d <= tol).all()), (fan, fu, fi, h1, h2, h3, float((d / tol).max()))
