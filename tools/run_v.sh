@@ -1,3 +1,6 @@
+# Runs on the GPU box: the bench line of the library in the tree and of every variant build named in $VARIANTS
+# (graphsage_amd/variants/libgsage_<name>.so, see tools/build_variant.sh), with $BENCH_ARGS.
+#   gpurun -- 'VARIANTS="a b" BENCH_ARGS="--workload cfg3" bash tools/run_v.sh > gpurun_out/v.log 2>&1'
 set -e
 cd $GRAFT_REPO_ROOT
 for v in "" $VARIANTS; do
