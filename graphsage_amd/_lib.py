@@ -112,6 +112,7 @@ class Sage2L0Mask(_c.Structure):
 
 
 SIGNATURES['gs_sage2_supported'] = (_i32, [_i32] * 6)
+SIGNATURES['gs_sage2_subtrees_supported'] = (_i32, [_i32] * 6)
 SIGNATURES['gs_sage2_forward'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
                                          _u64, _u64, _vp, _vp,
                                          _c.POINTER(SageWeights), _c.POINTER(SageWeights),

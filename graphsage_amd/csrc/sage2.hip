@@ -916,6 +916,10 @@ extern "C" int gs_sage2_supported(int Fu, int Fi, int H1, int H2, int n0, int n1
     return found && sage2_lds(Fu, Fi, H1, H2, n0, n1) <= kLdsMax;
 }
 
+extern "C" int gs_sage2_subtrees_supported(int Fu, int Fi, int H1, int H2, int n1, int n2) {
+    return gs_sage2_supported(Fu, Fi, H1, H2, n1, n2) && sage2_lds(Fu, Fi, H1, H2, n1, n2, kGroup) <= kLdsMax;
+}
+
 namespace {
 
 int sage2_forward_impl(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
@@ -969,8 +973,7 @@ int sage2_forward_impl(const int64_t *indptr, const int32_t *indices, int64_t n_
             return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: seeds given without out_hop1");
         if (sub->seeds && replay && sub->roots_per_walk > sub->tape_len)
             return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: the hops do not fit a tape of %lld words per walk", (long long)sub->tape_len);
-        if ((long long)kGroup * n0 * n1 > 4096 ||
-            sage2_lds(Fu, Fi, H1, H2, n0, n1, kGroup) > kLdsMax)
+        if (!gs_sage2_subtrees_supported(Fu, Fi, H1, H2, n0, n1))
             return gs::fail(GS_ELIMIT, "gs_sage2_forward_subtrees: fan-outs [%d,%d] are too large for %d subtrees per wavefront", n0, n1, kGroup);
     }
     a.key0 = (unsigned)rng_seed; a.key1 = (unsigned)(rng_seed >> 32); a.walk_base = walk_id_base;

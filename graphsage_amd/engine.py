@@ -136,7 +136,7 @@ class SageForwardEngine:
             subtree_kernel and use_fused and walk_kernel and self.n_hops == 3 and all(self.fused_layers) and not self.wide_first_layer_only
             and all(model.dims[l]['user'] == model.dims[l]['item'] for l in (1, 2, 3))
             and model._aggs[2]['user'].activation == model._aggs[2]['item'].activation
-            and kernels.sage2_supported(f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'], *self.fanouts[1:])
+            and kernels.sage2_subtrees_supported(f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'], *self.fanouts[1:])
             and kernels.sage3_seeds_supported(f['user'], f['item'], model.dims[1]['user'], model.dims[2]['user'],
                                               model.dims[3]['user'], self.fanouts[0]))
         self._subtree = None

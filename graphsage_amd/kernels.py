@@ -756,7 +756,8 @@ class Sage2Call:
         want = {(0, 'user'): (fu, fi, h1), (0, 'item'): (fi, fu, h1), (1, 'user'): (h1, h1, h2), (1, 'item'): (h1, h1, h2)}
         if dims != want:
             raise ValueError("weight shapes %s do not fit the model %s" % (dims, want))
-        if not lib.gs_sage2_supported(fu, fi, h1, h2, n0, n1):
+        query = lib.gs_sage2_subtrees_supported if subtrees is not None else lib.gs_sage2_supported
+        if not query(fu, fi, h1, h2, n0, n1):
             raise _lib.GsageError("the one-kernel forward does not cover Fu=%d Fi=%d H=[%d,%d] fan-outs [%d,%d]" %
                                   (fu, fi, h1, h2, n0, n1))
         dev = indptr.device
@@ -876,6 +877,10 @@ class Sage2Call:
                                          ptr(err_flag), stream_handle()),
               'gs_sage2_forward')
         return self.emb
+
+
+def sage2_subtrees_supported(fu, fi, h1, h2, n1, n2):
+    return bool(load().gs_sage2_subtrees_supported(int(fu), int(fi), int(h1), int(h2), int(n1), int(n2)))
 
 
 def sage3_seeds_supported(fu, fi, h1, h2, h3, n0):

@@ -469,7 +469,8 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
  * What remains for the caller are the seed nodes themselves: layer 0 and layer 1 at the seeds (neighbors: the
  * hop-1 nodes' feature rows / out_h0 rows) and layer 2 (neighbors: h1_out rows): gs_sage3_seeds_forward, or
  * gs_sage_fused_fwd per layer.
- * Shapes: gs_sage2_supported(Fu, Fi, H1, H2, n1, n2).
+ * Shapes: gs_sage2_subtrees_supported(Fu, Fi, H1, H2, n1, n2) != 0 (those of gs_sage2_supported whose eight
+ * subtrees' ids fit a wavefront's share of LDS); others get GS_ELIMIT.
  */
 typedef struct gs_sage2_subtrees {
     int32_t roots_per_walk;
@@ -479,6 +480,7 @@ typedef struct gs_sage2_subtrees {
     int32_t *out_hop1;
 } gs_sage2_subtrees;
 
+int gs_sage2_subtrees_supported(int Fu, int Fi, int H1, int H2, int n1, int n2);
 int gs_sage2_forward_subtrees(const int64_t *indptr, const int32_t *indices, int64_t n_nodes,
                               const float *feat_user, int64_t n_users, int Fu,
                               const float *feat_item, int64_t n_items, int Fi,

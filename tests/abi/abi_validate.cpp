@@ -256,6 +256,11 @@ int main() {
         REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, nullptr, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
     }
 
+    EXPECT(gs_sage2_subtrees_supported(64, 64, 32, 32, 10, 5) == 1);
+    EXPECT(gs_sage2_subtrees_supported(64, 64, 32, 32, 60, 60) == 0);      // supported as whole walks, too many ids for eight subtrees
+    EXPECT(gs_sage2_supported(64, 64, 32, 32, 60, 60) == 1);
+    EXPECT(gs_sage2_subtrees_supported(24, 19, 32, 32, 10, 5) == 0);
+
     // ---- layers 0, 1, 2 at the seeds of a three-hop model ----
     EXPECT(gs_sage3_seeds_supported(64, 64, 32, 32, 32, 25) == 1);
     EXPECT(gs_sage3_seeds_supported(64, 64, 32, 32, 48, 25) == 0);

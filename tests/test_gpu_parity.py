@@ -722,6 +722,34 @@ def test_subtree_route_with_isolated_and_invalid_seeds(cuda):
     assert torch.equal(got, h1) and torch.equal(out_h0, h0)
 
 
+def test_three_hop_fanouts_too_large_for_the_subtree_kernel_take_the_layered_route(cuda):
+    """Fan-outs whose eight subtrees' ids do not fit a wavefront's LDS share: the engine asks
+    gs_sage2_subtrees_supported, takes the sampler + one kernel per layer, and the results equal the general kernels'."""
+    from graphsage_amd.engine import SageForwardEngine
+    from graphsage_amd import kernels
+    rng = np.random.default_rng(12)
+    nu, ni, b = 200, 60, 4
+    u = np.concatenate([rng.integers(0, nu, 2000), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 2000), np.arange(nu) % ni]) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, 64)).astype(np.float32),
+             'item': rng.standard_normal((ni, 64)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    ns = [2, 60, 60]
+    assert kernels.sage2_supported(64, 64, 32, 32, 60, 60) and not kernels.sage2_subtrees_supported(64, 64, 32, 32, 60, 60)
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=4)
+    model = ga.GraphSAGE([32, 32, 32], gen, seed=6).build()
+    seeds = torch.tensor(list(e[0, :b]) + list(e[1, :b]), dtype=torch.int32, device=cuda)
+    eng = SageForwardEngine(g, model, b)
+    ref = SageForwardEngine(g, model, b, use_fused=False)
+    assert not eng.subtree_kernel and all(eng.fused_layers)
+    out = [x.clone() for x in eng.forward(seeds, None, rng_seed=2)]
+    want = [x.clone() for x in ref.forward(seeds, None, rng_seed=2)]
+    for a, c in zip(out, want):
+        close(a, c.double(), scale=float(c.abs().max()))
+
+
 def test_engine_wide_kernel_on_every_layer_matches_general_kernels(cuda):
     """A wide three-hop model with the row threshold lowered so that every layer -- dense activation
     rows from layer 1 on -- goes through the wide kernel: same embeddings as the general kernels."""
