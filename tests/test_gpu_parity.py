@@ -722,6 +722,50 @@ def test_subtree_route_with_isolated_and_invalid_seeds(cuda):
     assert torch.equal(got, h1) and torch.equal(out_h0, h0)
 
 
+def test_forward_pipeline_gives_each_batch_the_embeddings_of_a_plain_forward(cuda):
+    """Batches in flight on several streams (SageForwardEngine.pipeline): every batch's embeddings are bit for
+    bit those of forward() on that batch, also when a slot is reused."""
+    from graphsage_amd.engine import SageForwardEngine
+    rng = np.random.default_rng(21)
+    nu, ni, b = 500, 120, 64
+    u = np.concatenate([rng.integers(0, nu, 6000), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 6000), np.arange(nu) % ni]) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, 64)).astype(np.float32),
+             'item': rng.standard_normal((ni, 64)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, b, [8, 5], head_node_types=['user', 'item'], seed=4)
+    model = ga.GraphSAGE([32, 32], gen, seed=6).build()
+    eng = SageForwardEngine(g, model, b)
+    assert eng.walk_kernel
+    batches = [torch.tensor(list(e[0, k * b:(k + 1) * b]) + list(e[1, k * b:(k + 1) * b]), dtype=torch.int32, device=cuda)
+               for k in range(7)]
+    wid = [torch.arange(2 * b, dtype=torch.int64, device=cuda) + 1000 * k for k in range(7)]
+    want = [[x.clone() for x in eng.forward(s, w, rng_seed=5)] for s, w in zip(batches, wid)]
+    for depth in (1, 2, 3):
+        pipe = eng.pipeline(depth)
+        got = []
+        for s, w in zip(batches, wid):
+            eu, ei, ev = pipe.submit(s, w, rng_seed=5)
+            ev.synchronize()
+            got.append([eu.clone(), ei.clone()])
+        pipe.drain()
+        for a, c in zip(got, want):
+            assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+        # without waiting per batch: the last `depth` batches are still in their slots afterwards
+        outs = [pipe.submit(s, w, rng_seed=5) for s, w in zip(batches, wid)]
+        pipe.drain()
+        torch.cuda.synchronize()
+        for k in range(len(batches) - depth, len(batches)):
+            assert torch.equal(outs[k][0], want[k][0]) and torch.equal(outs[k][1], want[k][1])
+    assert eng.err_flag.tolist() == [0, 0]
+    three = ga.GraphSAGE([32, 32, 32], ga.GraphSAGEGenerator(g, b, [3, 3, 2], head_node_types=['user', 'item'], seed=4), seed=6).build()
+    from graphsage_amd._lib import GsageError
+    with pytest.raises(GsageError):
+        SageForwardEngine(g, three, b).pipeline(2)
+
+
 def test_three_hop_fanouts_too_large_for_the_subtree_kernel_take_the_layered_route(cuda):
     """Fan-outs whose eight subtrees' ids do not fit a wavefront's LDS share: the engine asks
     gs_sage2_subtrees_supported, takes the sampler + one kernel per layer, and the results equal the general kernels'."""
