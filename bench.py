@@ -363,6 +363,12 @@ def main():
         k = my_batches[i % len(my_batches)]
         return engine.forward(seeds[k], walk_ids[k], rng_seed=gen.sampler.seed)
 
+    # The collector stays out of the timed loops, as timeit keeps it: a full collection over the heap the graph
+    # build leaves behind takes tens of milliseconds, and in a process that has just compiled its modules it fell
+    # on the first timed step (0.9 ms per step reported for a 0.1 ms step).  It runs BEFORE the warm-up: a GPU left
+    # idle for those milliseconds right before the timed loop starts it at reduced clocks (+4 % per step measured).
+    gc.collect()
+    gc.disable()
     # warm-up covers every path of the timed loop, the event-carrying launch included: its first use creates
     # HIP events and pages code in (tens of milliseconds on a fresh machine), which belongs here
     scratch_probes = []
@@ -379,11 +385,6 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # The collector stays out of the timed loops, as timeit keeps it: a full collection over the heap the graph
-    # build leaves behind takes tens of milliseconds, and in a process that has just compiled its modules it fell
-    # on the first timed step (0.9 ms per step reported for a 0.1 ms step).
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     stamps = [] if os.environ.get('BENCH_STEP_TIMES') else None     # host time after each step's launches (debugging aid)
     for i in range(args.steps):
@@ -414,6 +415,8 @@ def main():
     # batch at a time, and `roofline` prices a launch that has the chip to itself.
     if engine.walk_kernel and not os.environ.get('BENCH_NO_PIPELINE'):
         pipe = engine.pipeline(2)
+        gc.collect()
+        gc.disable()
         for i in range(args.warmup):
             k = my_batches[i % len(my_batches)]
             pipe.submit(seeds[k], walk_ids[k], rng_seed=gen.sampler.seed, inputs_ready=True)
@@ -421,8 +424,6 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        gc.collect()
-        gc.disable()
         tp = time.perf_counter()
         for i in range(args.steps):
             k = my_batches[(args.warmup + i) % len(my_batches)]
@@ -486,6 +487,8 @@ def main():
                         print('[r%d] train warm-up step %d done' % (rank, i), file=sys.stderr, flush=True)
                 torch.cuda.synchronize()
 
+            gc.collect()
+            gc.disable()
             try:
                 warm_up()
             except Exception:
@@ -500,8 +503,6 @@ def main():
                 warm_up()
             if world > 1:
                 dist.barrier()
-            gc.collect()
-            gc.disable()
             t1 = time.perf_counter()
             for i in range(args.train_steps):
                 tstep(5 + i)
