@@ -600,7 +600,8 @@ class ForwardPipeline:
 
     ``submit`` returns the (user, item) embedding views of the slot it used and an event recorded behind the
     launch; the caller reads them (after ``event.synchronize()`` or ``torch.cuda.current_stream().wait_event``)
-    before ``depth`` further batches have been submitted, because the slot's rows are then written again.
+    before ``depth`` further batches have been submitted, because the slot's rows are then written again.  The
+    batch's input tensors are read on the slot's stream: they must stay allocated until that event has passed.
     """
 
     def __init__(self, engine, depth=2):
