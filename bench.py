@@ -413,7 +413,7 @@ def main():
     # secondary: the same K batches with two of them in flight (two streams, each with its own output rows):
     # what a caller that scores a stream of independent batches gets.  Not the headline: `value` above is one
     # batch at a time, and `roofline` prices a launch that has the chip to itself.
-    if engine.walk_kernel and not os.environ.get('BENCH_NO_PIPELINE'):
+    if (engine.walk_kernel or engine.subtree_kernel) and not os.environ.get('BENCH_NO_PIPELINE'):
         pipe = engine.pipeline(2)
         gc.collect()
         gc.disable()

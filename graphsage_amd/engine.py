@@ -401,6 +401,29 @@ class SageForwardEngine:
         """Several independent batches in flight (inference over a stream of batches): see ForwardPipeline."""
         return ForwardPipeline(self, depth)
 
+    def _make_subtree_state(self, hop1, emb, deeper_hops=None):
+        """The prepared calls of the two-launch three-hop route with their private buffers: the hop-1 ids go to
+        ``hop1``, the embeddings to ``emb`` (2*batch rows)."""
+        m, b = self.model, self.batch
+        n0, n1, n2 = self.fanouts
+        dev = self.indptr.device
+        h1w, h2w = m.dims[1]['user'], m.dims[2]['user']
+        st = {'h0': torch.empty((2 * b * n0, h1w), dtype=torch.float32, device=dev),       # layer 0 at the hop-1 nodes
+              'h1': torch.empty((2 * b * n0, h2w), dtype=torch.float32, device=dev)}       # layer 1 at the hop-1 nodes
+        weights = {(l, t): (m._aggs[l][t].w_self, m._aggs[l][t].w_neigh, m._aggs[l][t].bias)
+                   for l in (0, 1, 2) for t in _TYPES}
+        st['call'] = kernels.Sage2Call(
+            self.indptr, self.indices, self.tables['user'][0], self.tables['item'][0], [n1, n2],
+            {k: w for k, w in weights.items() if k[0] < 2}, False, b,
+            emb=st['h1'], hop_buffers=deeper_hops,
+            subtrees={'roots_per_walk': n0, 'tape_len': sum(self.sizes[1:]), 'tape_off_hop2': self.sizes[1],
+                      'tape_off_hop3': self.sizes[1] + self.sizes[2], 'out_h0': st['h0'],
+                      'draw_hop1': hop1.reshape(-1)})
+        st['seeds'] = kernels.Sage3SeedsCall(
+            self.tables['user'][0], self.tables['item'][0], hop1.reshape(-1), n0, st['h0'], st['h1'], weights,
+            m._aggs[2]['user'].activation, m.normalize == "l2", b, emb)
+        return st
+
     def forward_subtrees(self, seeds, walk_ids=None, rng_seed=0, replay=None):
         """Three hops in two launches: everything below the seeds in one kernel (all three hops drawn, layers 0 and
         1 computed per hop-1 node's subtree), then layers 0, 1, 2 at the seeds in a second one."""
@@ -414,23 +437,8 @@ class SageForwardEngine:
         if replay is not None and replay.numel() != seeds.numel() * tape_len:
             raise ValueError("replay tape has the wrong length")
         if self._subtree is None:
-            dev = self.indptr.device
-            h1w, h2w = m.dims[1]['user'], m.dims[2]['user']
-            st = {'h0': torch.empty((2 * b * n0, h1w), dtype=torch.float32, device=dev),       # layer 0 at the hop-1 nodes
-                  'h1': torch.empty((2 * b * n0, h2w), dtype=torch.float32, device=dev)}       # layer 1 at the hop-1 nodes
-            weights = {(l, t): (m._aggs[l][t].w_self, m._aggs[l][t].w_neigh, m._aggs[l][t].bias)
-                       for l in (0, 1, 2) for t in _TYPES}
-            st['call'] = kernels.Sage2Call(
-                self.indptr, self.indices, self.tables['user'][0], self.tables['item'][0], [n1, n2],
-                {k: w for k, w in weights.items() if k[0] < 2}, False, b,
-                emb=st['h1'], hop_buffers=(self.hops[1], self.hops[2]) if self.keep_ids else None,
-                subtrees={'roots_per_walk': n0, 'tape_len': tape_len, 'tape_off_hop2': self.sizes[1],
-                          'tape_off_hop3': self.sizes[1] + self.sizes[2], 'out_h0': st['h0'],
-                          'draw_hop1': self.hops[0].reshape(-1)})
-            st['seeds'] = kernels.Sage3SeedsCall(
-                self.tables['user'][0], self.tables['item'][0], self.hops[0].reshape(-1), n0, st['h0'], st['h1'], weights,
-                m._aggs[2]['user'].activation, m.normalize == "l2", b, self.emb_all)
-            self._subtree = st
+            self._subtree = self._make_subtree_state(self.hops[0], self.emb_all,
+                                                     (self.hops[1], self.hops[2]) if self.keep_ids else None)
         st = self._subtree
         if self.probes is not None:
             self._arm_probe()
@@ -588,8 +596,8 @@ class SageForwardEngine:
 
 
 class ForwardPipeline:
-    """``depth`` independent batches of the one-kernel forward in flight, each on a stream of its own with
-    its own output rows.
+    """``depth`` independent batches of the one-kernel forward (two hops) or of the two-launch forward (three
+    hops) in flight, each on a stream of its own with its own output rows.
 
     A launch of the one-kernel forward does not keep the whole chip busy to its end: the walks rooted at items
     finish well before those rooted at users (their deepest rows come from the smaller table), and within a side
@@ -605,15 +613,20 @@ class ForwardPipeline:
     """
 
     def __init__(self, engine, depth=2):
-        if not engine.walk_kernel:
-            raise kernels._lib.GsageError("the forward pipeline runs the two-hop one-kernel route")
+        if not (engine.walk_kernel or engine.subtree_kernel):
+            raise kernels._lib.GsageError("the forward pipeline runs the one-kernel (two hops) and two-launch (three "
+                                          "hops) routes")
         if depth < 1:
             raise ValueError("depth must be at least 1")
         self.engine = engine
         self.depth = int(depth)
         dev = engine.indptr.device
         self._emb = [torch.empty_like(engine.emb_all) for _ in range(self.depth)]
-        self._calls = [engine._make_walk_call(e) for e in self._emb]
+        if engine.walk_kernel:
+            self._calls = [engine._make_walk_call(e) for e in self._emb]
+        else:                                                    # every slot: its own hop-1 ids and hop-1 activations
+            self._hop1 = [torch.empty_like(engine.hops[0]) for _ in range(self.depth)]
+            self._states = [engine._make_subtree_state(h, e) for h, e in zip(self._hop1, self._emb)]
         self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)]
         self._events = [torch.cuda.Event() for _ in range(self.depth)]
         self._n = 0
@@ -629,7 +642,12 @@ class ForwardPipeline:
         if not inputs_ready:
             stream.wait_stream(torch.cuda.current_stream())      # the batch's inputs were produced there
         with torch.cuda.stream(stream):
-            self._calls[slot].run(seeds, eng.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
+            if eng.walk_kernel:
+                self._calls[slot].run(seeds, eng.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
+            else:
+                st = self._states[slot]
+                st['call'].run(seeds, eng.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
+                st['seeds'].run(seeds)
             self._events[slot].record(stream)
         emb = self._emb[slot]
         return emb[:b], emb[b:], self._events[slot]

@@ -760,10 +760,22 @@ def test_forward_pipeline_gives_each_batch_the_embeddings_of_a_plain_forward(cud
         for k in range(len(batches) - depth, len(batches)):
             assert torch.equal(outs[k][0], want[k][0]) and torch.equal(outs[k][1], want[k][1])
     assert eng.err_flag.tolist() == [0, 0]
+    # three hops: the two-launch route, every slot with its own hop-1 ids and activations
     three = ga.GraphSAGE([32, 32, 32], ga.GraphSAGEGenerator(g, b, [3, 3, 2], head_node_types=['user', 'item'], seed=4), seed=6).build()
+    eng3 = SageForwardEngine(g, three, b)
+    assert eng3.subtree_kernel
+    want3 = [[x.clone() for x in eng3.forward(s, w, rng_seed=5)] for s, w in zip(batches, wid)]
+    pipe = eng3.pipeline(2)
+    outs = []
+    for s, w in zip(batches, wid):
+        eu, ei, ev = pipe.submit(s, w, rng_seed=5)
+        ev.synchronize()
+        outs.append([eu.clone(), ei.clone()])
+    for a, c in zip(outs, want3):
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
     from graphsage_amd._lib import GsageError
-    with pytest.raises(GsageError):
-        SageForwardEngine(g, three, b).pipeline(2)
+    with pytest.raises(GsageError):                                # the layered routes share their buffers
+        SageForwardEngine(g, three, b, subtree_kernel=False).pipeline(2)
 
 
 def test_three_hop_fanouts_too_large_for_the_subtree_kernel_take_the_layered_route(cuda):
