@@ -179,6 +179,7 @@ class Trainer:
         self.opt = Adam(self.params, self.bucket.flat, lr=lr, params_flat=self.bucket.flat_params)
         self._head_step = None
         self._fwd_engine = None
+        self._fwd_pipe = None                                # two batches in flight for evaluate / predict
         self._graph_obj, self._batch_size = graph, batch_size
         self.group = group
         self.engine = None
@@ -438,6 +439,46 @@ class Trainer:
         batch, y = seq[i]
         return self.head(self.model(batch)), y
 
+    @torch.no_grad()
+    def _score_stream(self, seq):
+        """(scores, targets) of every batch of ``seq`` in order.  Full batches of a keyed sequence go through the
+        forward engine with two batches in flight where its route allows (``SageForwardEngine.pipeline``): batch
+        i + 1 is launched before batch i's embeddings are scored, and a slot's rows are scored on this stream
+        before the slot's stream is allowed to write them again (``submit`` makes it wait for this stream)."""
+        n = len(seq)
+        use_engine = (self._graph_obj is not None and self._batch_size and getattr(seq, '_indexed', False)
+                      and seq.batch_size == int(self._batch_size) and not (self.model.dropout and self.model.training))
+        n_eng = 0
+        if use_engine:
+            staged = seq.epoch_on_device()
+            n_eng = min(n, staged['n_batches'])
+            if self._fwd_engine is None:
+                from .engine import SageForwardEngine
+                self._fwd_engine = SageForwardEngine(self._graph_obj, self.model, self._batch_size)
+            eng = self._fwd_engine
+        if n_eng >= 2 and (eng.walk_kernel or eng.subtree_kernel):
+            if self._fwd_pipe is None:
+                self._fwd_pipe = eng.pipeline(2)
+            pipe, cur = self._fwd_pipe, torch.cuda.current_stream()
+
+            def score(i, out):
+                cur.wait_event(out[2])
+                y = None if staged['targets'] is None else staged['targets'][i]
+                return self.head((out[0], out[1])), y
+            pending = None
+            for i in range(n_eng):
+                out = pipe.submit(staged['roots'][i], staged['walk_ids'][i], rng_seed=staged['key'])
+                if pending is not None:
+                    yield score(i - 1, pending)
+                pending = out
+            yield score(n_eng - 1, pending)
+            pipe.drain()
+        else:
+            for i in range(n_eng):
+                yield self._scores(seq, i)
+        for i in range(n_eng, n):
+            yield self._scores(seq, i)
+
     def _inference(self):
         """Context in which the model runs with dropout off, as Keras runs ``evaluate``, ``predict`` and the
         validation pass of ``fit`` (``train_movielens.py:200-207``); the training flag is restored after."""
@@ -459,8 +500,7 @@ class Trainer:
         dev = self.bucket.flat.device
         ys, preds = [], []
         with self._inference():
-            for i in range(len(seq)):
-                pred, y = self._scores(seq, i)
+            for pred, y in self._score_stream(seq):
                 ys.append((y if isinstance(y, torch.Tensor)
                            else torch.as_tensor(np.asarray(y, dtype=np.float32), device=dev)).reshape(-1))
                 preds.append(pred.reshape(-1))
@@ -472,7 +512,7 @@ class Trainer:
     def predict(self, seq):
         """Scores of every link of a sequence, in sequence order: float32 [n, 1] (no dropout)."""
         with self._inference():
-            return torch.cat([self._scores(seq, i)[0] for i in range(len(seq))])
+            return torch.cat([pred for pred, _ in self._score_stream(seq)])
 
     def step(self, batch, targets):
         self.bucket.zero()

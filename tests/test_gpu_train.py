@@ -610,6 +610,31 @@ def test_evaluate_and_predict_run_without_dropout(cuda):
     assert not torch.equal(x1[0], x2[0])
 
 
+@pytest.mark.parametrize('ns', [[4, 3], [3, 3, 2]])
+def test_predict_and_evaluate_with_two_batches_in_flight_equal_batch_by_batch_scoring(cuda, ns):
+    """evaluate / predict keep two batches in flight on the one-kernel (two hops) and two-launch (three hops)
+    routes: the scores are bit for bit those of scoring batch after batch, short last batch included."""
+    from graphsage_amd.train import LinkHead
+    g, links, targets = _toy(3, fu=64, fi=64)
+    b = 16
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=1)
+    model = ga.GraphSAGE([32] * len(ns), gen, seed=2)
+    tr = Trainer(model, head=LinkHead(32, cuda, seed=5), lr=1e-2, graph=g, batch_size=b)
+    n = 5 * b + 7                                                  # five full batches and a short one
+    seq = gen.flow(links[:n], targets=targets[:n], shuffle=False)
+    with torch.no_grad(), tr._inference():
+        want = torch.cat([tr._scores(seq, i)[0] for i in range(len(seq))])
+    assert tr._fwd_engine is not None and (tr._fwd_engine.walk_kernel or tr._fwd_engine.subtree_kernel)
+    got = tr.predict(seq)
+    assert tr._fwd_pipe is not None
+    assert got.shape == (n, 1) and torch.equal(got, want)
+    again = tr.predict(seq)                                        # the slots are reused
+    assert torch.equal(again, want)
+    ev = tr.evaluate(seq)
+    y = torch.from_numpy(np.asarray(targets[:n], dtype=np.float32)).to(cuda)
+    assert abs(ev['loss'] - float(((want.reshape(-1).double() - y.double()) ** 2).mean())) < 1e-6
+
+
 def test_sequences_of_one_generator_draw_independently_and_leave_the_walker_seed_alone(cuda):
     g, links, targets = _toy(2, fu=32, fi=32)
     gen = ga.GraphSAGEGenerator(g, 16, [5, 3], head_node_types=['user', 'item'], seed=77)
