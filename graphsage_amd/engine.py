@@ -364,8 +364,19 @@ class SageForwardEngine:
             self._run_fused_layer(layer, seeds)
         return self.emb['user'], self.emb['item']
 
-    def _refresh_padded_weights(self):
-        m, pad = self.model, self._padded
+    def _private_padded(self):
+        """A second set of padded layer-0 weights over the same padded tables (a pipeline slot refreshes and reads
+        its own copy on its own stream); None when the engine does not pad."""
+        if self._padded is None:
+            return None
+        return {'tables': self._padded['tables'], 'weights': {k: torch.zeros_like(w) for k, w in self._padded['weights'].items()},
+                'fresh': False}
+
+    def _refresh_padded_weights(self, pad=None):
+        """Copies the real layer-0 weights into the zero-padded ones, on the CURRENT stream: the launch that reads
+        them must be ordered behind this call on that stream."""
+        m = self.model
+        pad = self._padded if pad is None else pad
         if pad is not None and not (self.static_weights and pad['fresh']):
             with torch.no_grad():
                 for t in _TYPES:
@@ -374,9 +385,11 @@ class SageForwardEngine:
                     pad['weights'][(t, 'neigh')][:agg.w_neigh.shape[0]].copy_(agg.w_neigh)
             pad['fresh'] = True
 
-    def _make_walk_call(self, emb):
-        """A prepared one-kernel forward that writes its embeddings to ``emb`` (2*batch rows)."""
-        m, pad = self.model, self._padded
+    def _make_walk_call(self, emb, pad=None):
+        """A prepared one-kernel forward that writes its embeddings to ``emb`` (2*batch rows); ``pad``: the set of
+        padded weights it reads (default: the engine's own)."""
+        m = self.model
+        pad = self._padded if pad is None else pad
         weights = {(l, t): (m._aggs[l][t].w_self, m._aggs[l][t].w_neigh, m._aggs[l][t].bias)
                    for l in (0, 1) for t in _TYPES}
         tables = {t: self.tables[t][0] for t in _TYPES}
@@ -623,7 +636,10 @@ class ForwardPipeline:
         dev = engine.indptr.device
         self._emb = [torch.empty_like(engine.emb_all) for _ in range(self.depth)]
         if engine.walk_kernel:
-            self._calls = [engine._make_walk_call(e) for e in self._emb]
+            # odd feature widths: every slot keeps padded layer-0 weights of its own, refreshed on the slot's stream
+            # right before its launch, so no copy ever runs beside a launch that reads its destination
+            self._pads = [engine._private_padded() for _ in range(self.depth)]
+            self._calls = [engine._make_walk_call(e, pad) for e, pad in zip(self._emb, self._pads)]
         else:                                                    # every slot: its own hop-1 ids and hop-1 activations
             self._hop1 = [torch.empty_like(engine.hops[0]) for _ in range(self.depth)]
             self._states = [engine._make_subtree_state(h, e) for h, e in zip(self._hop1, self._emb)]
@@ -632,17 +648,18 @@ class ForwardPipeline:
         self._n = 0
 
     def submit(self, seeds, walk_ids=None, rng_seed=0, replay=None, inputs_ready=False):
-        """``inputs_ready``: the batch's tensors are complete already (resident since an earlier synchronisation),
-        so the slot's stream need not wait for the current stream."""
+        """``inputs_ready``: the batch's tensors AND the model's weights are complete already (resident since an
+        earlier synchronisation), so the slot's stream need not wait for the current stream."""
         eng, b = self.engine, self.engine.batch
         slot = self._n % self.depth
         self._n += 1
-        eng._refresh_padded_weights()
         stream = self._streams[slot]
         if not inputs_ready:
             stream.wait_stream(torch.cuda.current_stream())      # the batch's inputs were produced there
         with torch.cuda.stream(stream):
             if eng.walk_kernel:
+                # (the slot's previous launch, the only other user of these copies, is ahead on this stream)
+                eng._refresh_padded_weights(self._pads[slot])
                 self._calls[slot].run(seeds, eng.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
             else:
                 st = self._states[slot]

@@ -166,10 +166,29 @@ class Trainer:
     """One optimisation step = batch -> embeddings -> head -> MSE -> backward ->
     gradient all-reduce -> Adam."""
 
-    def __init__(self, model, head=None, lr=1e-2, group=None, engine='auto', graph=None, batch_size=None):
+    def __init__(self, model, head=None, lr=1e-2, group=None, engine='auto', graph=None, batch_size=None,
+                 overlap='none', collective_at_world_one=False):
         """engine: 'autograd' runs the model through torch.autograd Functions (any
         shape); 'plan' uses the static launch plan of ``SageTrainEngine`` (needs
-        ``graph`` and ``batch_size``); 'auto' picks the plan when it applies."""
+        ``graph`` and ``batch_size``); 'auto' picks the plan when it applies.
+
+        overlap: how ``step_graph`` runs the gradient all-reduce when there is more than one rank.
+        'none': replayed graph (sampling, forward, backward), then the collective, then one update launch.
+        'capture': the collective and the update are captured INSIDE the graph, a step is one replay (needs a
+        backend whose collectives are stream operations: RCCL).
+        'delayed': step k's gradients are copied aside and all-reduced on a second stream while step k + 1's
+        forward and backward run; they are applied after step k + 1's backward (the weights a step reads are one
+        update behind; ``flush()`` applies the last one).
+        collective_at_world_one: treat a process group of one rank like a larger one (the collective is issued
+        all the same): lets a single GPU rehearse the 'capture' and 'delayed' paths."""
+        if overlap not in ('none', 'capture', 'delayed'):
+            raise ValueError("overlap must be 'none', 'capture' or 'delayed'")
+        self.overlap = overlap
+        self._collective_always = bool(collective_at_world_one)
+        self._pending = None                                 # delayed mode: (work, buffer, 1 / world) of the last step
+        self._send = None
+        self._coll_stream = None
+        self._n_graph_steps = 0
         self.model = model.build()
         dev = self.model.parameters()[0].device
         emb_dim = self.model.dims[-1]['user']
@@ -266,26 +285,75 @@ class Trainer:
         return True
 
     # -- HIP-graph replay of the step ---------------------------------------------------
-    def _graph_body(self, with_update):
+    def _ranks(self):
+        """(more than one rank -- or one rank asked to behave like several --, world size)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False, 1
+        world = dist.get_world_size(self.group)
+        return world > 1 or self._collective_always, world
+
+    def _graph_body(self, with_update, with_collective=False):
+        import torch.distributed as dist
         from . import kernels
         eng = self.engine
         emb_u, emb_i = eng.forward_train(eng.seeds_buf, self._walk_buf, self._graph_seed)
         self._head_and_backward(emb_u, emb_i, self._target_buf)
+        scale = 1.0
+        if with_collective:
+            # the sum over ranks as a node of the graph; the update reads the gradients times 1 / world
+            dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
+            scale = 1.0 / dist.get_world_size(self.group)
         if with_update:
             kernels.adam_step(self.opt.p_flat, self.opt.g, self.opt.m, self.opt.v, 0.0, self.opt.b1, self.opt.b2,
-                              self.opt.eps, lr_t_device=self.opt.lr_dev)
+                              self.opt.eps, grad_scale=scale, lr_t_device=self.opt.lr_dev)
+
+    def _start_delayed_all_reduce(self):
+        """Copies this step's gradients aside and starts their all-reduce on the collective stream; returns what
+        ``_apply_delayed`` needs.  The next replay may overwrite the bucket at once."""
+        import torch.distributed as dist
+        main = torch.cuda.current_stream()
+        if self._send is None:
+            self._send = [torch.empty_like(self.bucket.flat) for _ in range(2)]
+            self._coll_stream = torch.cuda.Stream()
+        buf = self._send[self._n_graph_steps % 2]
+        buf.copy_(self.bucket.flat)
+        side = self._coll_stream
+        side.wait_stream(main)
+        if dist.get_backend(self.group) == 'gloo':
+            side.synchronize()                               # gloo stages device tensors through the host
+        with torch.cuda.stream(side):
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return work, buf, 1.0 / dist.get_world_size(self.group)
+
+    def _apply_delayed(self, pending):
+        from . import kernels
+        work, buf, scale = pending
+        with torch.cuda.stream(self._coll_stream):
+            work.wait()
+        torch.cuda.current_stream().wait_stream(self._coll_stream)
+        kernels.adam_step(self.opt.p_flat, buf, self.opt.m, self.opt.v, self.opt.next_rate(), self.opt.b1, self.opt.b2,
+                          self.opt.eps, grad_scale=scale)
+
+    def flush(self):
+        """Applies the update a 'delayed' step left pending (call before reading or saving the weights)."""
+        if self._pending is not None:
+            pending, self._pending = self._pending, None
+            self._apply_delayed(pending)
 
     def step_graph(self, seeds, targets, walk_ids, rng_seed=0):
         """``step_device`` as a captured HIP graph: the ~30 launches of a step are
         replayed by one call, which removes the per-launch host cost.  Inputs are
         copied into static buffers; the sampling key is fixed at capture (draws
         still differ per link through ``walk_ids``), so a new ``rng_seed`` - a new
-        epoch - recaptures.  With more than one rank the all-reduce stays outside
-        the graph, between the gradient graph and the update kernel."""
-        import torch.distributed as dist
+        epoch - recaptures.  With more than one rank the all-reduce runs as
+        ``overlap`` says (constructor): after the graph, inside it, or beside the
+        next step."""
         from . import kernels
         eng = self.engine
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        multi, _ = self._ranks()
+        in_graph = multi and self.overlap == 'capture'       # collective + update are graph nodes
+        outside = multi and not in_graph                     # the graph ends after backward
         if self._prepare_head_step():
             self._graph = None                               # captured addresses are those of the old layout
         if getattr(self, '_graph', None) is None or self._graph_seed != rng_seed:
@@ -302,7 +370,7 @@ class Trainer:
             with torch.cuda.stream(side):                # warm-up outside capture (lazy plan construction)
                 self.opt.lr_dev.zero_()                  # rate 0: the warm-up must not move the weights
                 m_save, v_save = self.opt.m.clone(), self.opt.v.clone()
-                self._graph_body(not multi)
+                self._graph_body(not outside, in_graph)  # (an in-graph collective runs here too, on every rank)
                 self.opt.m.copy_(m_save)
                 self.opt.v.copy_(v_save)
             torch.cuda.current_stream().wait_stream(side)
@@ -311,27 +379,32 @@ class Trainer:
             # while this thread captures
             torch.cuda.synchronize()
             with torch.cuda.graph(self._graph, capture_error_mode='thread_local'):
-                self._graph_body(not multi)
+                self._graph_body(not outside, in_graph)
         def fits(src, dst):
             return (isinstance(src, torch.Tensor) and src.device == dst.device and src.dtype == dst.dtype
                     and src.is_contiguous() and src.numel() == dst.numel())
         if fits(seeds, eng.seeds_buf) and fits(walk_ids, self._walk_buf) and fits(targets, self._target_buf):
             # the usual case (rows of an epoch staged on the device): inputs and rate in one launch
             kernels.stage_batch(seeds, eng.seeds_buf, walk_ids, self._walk_buf, targets, self._target_buf,
-                                0.0 if multi else self.opt.next_rate(), None if multi else self.opt.lr_dev)
+                                0.0 if outside else self.opt.next_rate(), None if outside else self.opt.lr_dev)
         else:
             eng.seeds_buf.copy_(seeds)
             self._walk_buf.copy_(walk_ids)
             self._target_buf.copy_(targets)
-            if not multi:
+            if not outside:
                 self.opt.step(launch=False)              # sets the device-side rate for this step
-        if multi:
+        self._graph.replay()
+        if outside and self.overlap == 'delayed':
+            # this step's gradients travel while the next step computes; the previous step's arrive now
+            started = self._start_delayed_all_reduce()
+            if self._pending is not None:
+                self._apply_delayed(self._pending)
+            self._pending = started
+        elif outside:
             # sampling + forward + backward replayed as one graph; then ONE collective (sum) and ONE update
             # launch that applies 1 / world to the gradients as it reads them
-            self._graph.replay()
             self.opt.step(grad_scale=self.bucket.all_reduce_sum(self.group))
-        else:
-            self._graph.replay()
+        self._n_graph_steps += 1
         return self._head_step.loss, self._head_step.pred.reshape(-1, 1)
 
     # -- Keras-style loops over a LinkSequence ------------------------------------------
@@ -382,6 +455,7 @@ class Trainer:
                 ys.append(y_dev.reshape(-1))
                 preds.append(pred.detach().reshape(-1).clone())
                 losses.append(loss.detach().reshape(1).clone())
+            self.flush()                                       # (delayed mode: the last step's update)
             logs = self._epoch_logs(mets, ys, preds, losses)
             self._raise_sampling_errors()
             if validation_data is not None:
@@ -499,6 +573,7 @@ class Trainer:
         """Loss and metrics of the current weights over a sequence (no update, no dropout)."""
         dev = self.bucket.flat.device
         ys, preds = [], []
+        self.flush()
         with self._inference():
             for pred, y in self._score_stream(seq):
                 ys.append((y if isinstance(y, torch.Tensor)
@@ -511,6 +586,7 @@ class Trainer:
     @torch.no_grad()
     def predict(self, seq):
         """Scores of every link of a sequence, in sequence order: float32 [n, 1] (no dropout)."""
+        self.flush()
         with self._inference():
             return torch.cat([pred for pred, _ in self._score_stream(seq)])
 

@@ -778,6 +778,49 @@ def test_forward_pipeline_gives_each_batch_the_embeddings_of_a_plain_forward(cud
         SageForwardEngine(g, three, b, subtree_kernel=False).pipeline(2)
 
 
+def test_forward_pipeline_on_padded_feature_widths_reads_the_current_weights(cuda):
+    """Odd feature widths (28 / 18) run on zero-padded tables and padded copies of the layer-0 weights.  A
+    pipeline slot refreshes its own copy on its own stream: the very first call may say inputs_ready, and
+    weights changed between submits are the ones the next launch reads."""
+    from graphsage_amd.engine import SageForwardEngine
+    rng = np.random.default_rng(22)
+    nu, ni, b = 300, 90, 48
+    u = np.concatenate([rng.integers(0, nu, 4000), np.arange(nu)])
+    it = np.concatenate([rng.integers(0, ni, 4000), np.arange(nu) % ni]) + nu
+    e = np.stack([u, it])
+    feats = {'user': rng.standard_normal((nu, 28)).astype(np.float32),
+             'item': rng.standard_normal((ni, 18)).astype(np.float32)}
+    g = ga.Graph(feats, {'user': list(range(nu)), 'item': list(range(nu, nu + ni))},
+                 np.concatenate([e, e[::-1]], axis=1))
+    gen = ga.GraphSAGEGenerator(g, b, [6, 4], head_node_types=['user', 'item'], seed=4)
+    model = ga.GraphSAGE([32, 32], gen, seed=6).build()
+    batches = [torch.tensor(list(e[0, k * b:(k + 1) * b]) + list(e[1, k * b:(k + 1) * b]), dtype=torch.int32, device=cuda)
+               for k in range(5)]
+    wid = [torch.arange(2 * b, dtype=torch.int64, device=cuda) + 1000 * k for k in range(5)]
+    eng = SageForwardEngine(g, model, b)
+    assert eng.walk_kernel and eng._padded is not None
+    pipe = eng.pipeline(2)
+    torch.cuda.synchronize()
+    # first call ever on this engine, inputs_ready: nothing on the current stream orders the weight copies
+    first = pipe.submit(batches[0], wid[0], rng_seed=5, inputs_ready=True)
+    first[2].synchronize()
+    ref = SageForwardEngine(g, model, b)
+    want = ref.forward(batches[0], wid[0], rng_seed=5)
+    assert torch.equal(first[0], want[0]) and torch.equal(first[1], want[1])
+    # the weights move between submits (a training loop scoring as it goes): each launch reads what is there
+    for k in range(1, 5):
+        with torch.no_grad():
+            for t in ('user', 'item'):
+                model._aggs[0][t].w_self.mul_(1.0 + 0.1 * k)
+                model._aggs[0][t].w_neigh.add_(0.01 * k)
+        out = pipe.submit(batches[k], wid[k], rng_seed=5)
+        want = [x.clone() for x in ref.forward(batches[k], wid[k], rng_seed=5)]
+        out[2].synchronize()
+        assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+    pipe.drain()
+    assert eng.err_flag.tolist() == [0, 0]
+
+
 def test_three_hop_fanouts_too_large_for_the_subtree_kernel_take_the_layered_route(cuda):
     """Fan-outs whose eight subtrees' ids do not fit a wavefront's LDS share: the engine asks
     gs_sage2_subtrees_supported, takes the sampler + one kernel per layer, and the results equal the general kernels'."""
