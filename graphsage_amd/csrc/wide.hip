@@ -47,6 +47,18 @@
 
 namespace {
 
+// Diagnostic build (-DGS_WIDE_STAMP, tools/build_variant.sh): shader-clock stamps around the waits and phases of
+// one producer and one consumer wave of two blocks, printed when the block ends.  No stamp executes otherwise.
+#ifdef GS_WIDE_STAMP
+#define STAMP(v_) const long long v_ = clock64();
+#define STAMP_ADD(acc_, v_) acc_ += clock64() - v_;
+#define STAMP_VARS(...) long long __VA_ARGS__;
+#else
+#define STAMP(v_)
+#define STAMP_ADD(acc_, v_)
+#define STAMP_VARS(...)
+#endif
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 // Pointers built from integers are generic to the compiler, and a generic ("flat") access may be an
 // LDS access: while one is pending every wait for a load becomes a wait for all of them.  These
@@ -514,6 +526,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         WD_BEGIN(s0)
         WD_BEGIN(s1)
         int stage = 0;
+        STAMP_VARS(t_empty[2] = {0, 0}, t_fin[2] = {0, 0}, t_ids = 0, t_beg[2] = {0, 0}, t_begin = clock64())
         uint32_t use = 0;                                          // times `stage` has been filled before
         // Slice g: wait until the consumers have read what the stage held, move the slice from registers
         // to the stage (its loads were issued two slices ago), then the freed registers take the loads of
@@ -521,16 +534,21 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         // of the row loads of that slice; one slice later they have arrived and go to the id patch.
         bool ids_wait = false;                                     // id loads in flight, issued in the previous slice
 #define WD_PRODUCE(S_, O_)                                                                          \
-            pr.finish(S_, stage, O_.cnt, ids_wait);                                                 \
+            STAMP(tf0) pr.finish(S_, stage, O_.cnt, ids_wait);                                      \
             flag_add(full + stage);                                                                 \
+            STAMP_ADD(t_fin[cc.side], tf0) STAMP(ti0)                                               \
             if (ids_wait) { pr.ids_commit(next_tile, (cc.local + 1) & 1, O_.cnt); ids_wait = false; } \
             if (stage_ids) { pr.ids_issue(next_tile); ids_wait = true; }                            \
-            WD_BEGIN(S_)
+            STAMP_ADD(t_ids, ti0) STAMP_VARS(bside = cl.side) STAMP(tb0)                            \
+            WD_BEGIN(S_)                                                                            \
+            STAMP_ADD(t_beg[bside], tb0)
 #define WD_TICK(S_, O_)                                                                             \
         {                                                                                           \
             const int next_tile = cc.tile + sh.stride;                                              \
             const bool stage_ids = cc.ct == 0 && cc.side == 0 && cc.ks == 0 && next_tile < n_tiles; \
+            STAMP(t0s)                                                                              \
             if (use && !flag_wait(empty + stage, use * kConsumerWaves, flag_peek(empty + stage))) stalled = true; \
+            STAMP_ADD(t_empty[cc.side], t0s)                                                        \
             WD_PRODUCE(S_, O_)                                                                      \
             advance(cc, sh, a);                                                                     \
             if (++stage == kStages) { stage = 0; ++use; }                                           \
@@ -545,6 +563,11 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
 #undef WD_NEXT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the surplus loads
         if (stalled && (tid & 63) == 0) a.out[0] = __builtin_nanf("");
+#ifdef GS_WIDE_STAMP
+        if ((tid & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && (tid >> 6) == 9)
+            printf("blk %d producer: total %lld  wait-empty %lld/%lld  finish %lld/%lld  ids %lld  begin %lld/%lld  (own rows/neighbors) slices %d\n",
+                   (int)blockIdx.x, clock64() - t_begin, t_empty[0], t_empty[1], t_fin[0], t_fin[1], t_ids, t_beg[0], t_beg[1], T);
+#endif
         return;
     }
 
@@ -638,6 +661,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     if (!flag_wait(full, kProducerWaves, flag_peek(full))) stalled = true;
     WD_READ_A(X, st, 0, a_slot0);
     int stage = 0;
+    STAMP_VARS(t_full[2] = {0, 0}, t_epi = 0, t_begin = clock64())
     uint32_t use = 1;                                               // times the stage of slice g has been filled, this one included
     for (int g = 0; g < T; ++g) {
         const float *S = st + stage * W_TILE;
@@ -651,19 +675,30 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         WD_B_BASE(cn, 0)
         WD_STEP(X, 0) WD_STEP(X, 1) WD_STEP(X, 2) WD_STEP(X, 3)
         if (g + 1 < T) {
+            STAMP(t0f)
             if (!flag_wait(full + nstage, nuse * kProducerWaves, seen)) stalled = true;
+            STAMP_ADD(t_full[cn.side], t0f)
             WD_READ_A(X, st + nstage * W_TILE, 0, a_slot0);
         }
         __builtin_amdgcn_sched_barrier(0);
         WD_B_BASE(cn, 1)
         WD_STEP(Y, 0) WD_STEP(Y, 1) WD_STEP(Y, 2) WD_STEP(Y, 3)
-        if (c.ks + 1 == (c.side ? sh.nn : sh.ns)) epilogue(c);
+        if (c.ks + 1 == (c.side ? sh.nn : sh.ns)) {
+            STAMP(t0e)
+            epilogue(c);
+            STAMP_ADD(t_epi, t0e)
+        }
         advance(c, sh, a);
         if (g + 2 < T) advance(cn, sh, a);
         stage = nstage;
         use = nuse;
     }
     if (stalled && lane == 0) a.out[0] = __builtin_nanf("");
+#ifdef GS_WIDE_STAMP
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && wave == 1)
+        printf("blk %d consumer: total %lld  wait-full %lld/%lld  epilogue %lld  slices %d\n", (int)blockIdx.x, clock64() - t_begin,
+               t_full[0], t_full[1], t_epi, T);
+#endif
 #undef WD_READ_A
 #undef WD_MFMA_ROW
 #undef WD_MFMA_STEP
