@@ -39,6 +39,23 @@ inline void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
 }
 
+// Raises a kernel's dynamic-LDS limit.  The attribute belongs to the (kernel, device) pair, so what has been
+// done is remembered per pair: a host thread that moves to another GPU raises the limit there as well.
+inline hipError_t raise_lds_limit(const void *kernel, int bytes) {
+    struct Done { const void *kernel; int device; };
+    constexpr int kSlots = 64;
+    static thread_local Done done[kSlots];
+    static thread_local int n_done = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < n_done; ++i)
+        if (done[i].kernel == kernel && done[i].device == dev) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && n_done < kSlots) done[n_done++] = Done{kernel, dev};     // (a full table only costs the call)
+    return e;
+}
+
 constexpr int kWave = 64;
 
 __host__ __device__ inline int ilog2_ceil(int v) {

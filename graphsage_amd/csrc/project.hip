@@ -1033,8 +1033,7 @@ int project_fwd(const float *x_self, const int32_t *self_ids, int64_t off_self, 
     const int by = s0.ncb + s1.ncb;
     if (bx > 0x7FFFFFFFLL || by > 65535) return gs::fail(GS_ELIMIT, "gs_sage_project_fwd: grid %lld x %d too large", (long long)bx, by);
     if (big_gemm_applies(s0) && big_gemm_applies(s1) && M >= 4 * GB_M) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rows_gemm_big_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS);
+        const hipError_t attr = gs::raise_lds_limit(reinterpret_cast<const void *>(rows_gemm_big_kernel), (int)GB_LDS);
         if (attr != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage_project_fwd: LDS attribute: %s", hipGetErrorString(attr));
         const int64_t gx = (M + GB_M - 1) / GB_M;
         const int gy = 2 * (Hh / GB_N);
@@ -1097,8 +1096,7 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
         float *slab1 = slab0 + (size_t)nc * (Fs + 1) * Hh;
         bool direct = false;
         if (M > 0 && wgrad_big_applies(Fs, Fn, Hh, H, x_self, x_mean, g_out, mask)) {
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_big_kernel),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS);
+            const hipError_t attr = gs::raise_lds_limit(reinterpret_cast<const void *>(wgrad_big_kernel), (int)WB_LDS);
             if (attr != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage_project_bwd: %s", hipGetErrorString(attr));
             WgradSide a{}, b{};
             a.X = x_self; a.G = g_out; a.mask = mask; a.slab = slab0; a.K = Fs; a.N = Hh; a.ldg = H;
@@ -1157,8 +1155,7 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
         // wide layers: both input gradients on the 128x128-tile kernel (a side that is not wanted has N = 0)
         const bool big0 = s0.N == 0 || big_gemm_applies(s0), big1 = s1.N == 0 || big_gemm_applies(s1);
         if (big0 && big1 && M >= 4 * GB_M) {
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rows_gemm_big_kernel),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS);
+            const hipError_t attr = gs::raise_lds_limit(reinterpret_cast<const void *>(rows_gemm_big_kernel), (int)GB_LDS);
             if (attr != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage_project_bwd: %s", hipGetErrorString(attr));
             const int64_t gx = (M + GB_M - 1) / GB_M;
             const int gy = s0.N / GB_N + s1.N / GB_N;

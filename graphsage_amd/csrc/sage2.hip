@@ -874,11 +874,9 @@ int launch_one(const Sage2Args &a, hipStream_t stream) {
     const size_t lds = S::lds_bytes(a.n0, a.n1, waves, roots);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
     auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF, SAVE, SUB>;
-    static thread_local const void *configured = nullptr;
-    if (lds > 64 * 1024 && configured != (const void *)kern) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    if (lds > 64 * 1024) {
+        hipError_t e = gs::raise_lds_limit((const void *)kern, (int)kLdsMax);
         if (e != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage2_forward: cannot raise the LDS limit: %s", hipGetErrorString(e));
-        configured = (const void *)kern;
     }
     long long blocks = 2 * ((a.n_pairs + waves - 1) / waves);   // even blocks: user roots, odd: item roots
     if (blocks > 256) blocks = 256;                      // one block per CU, waves loop over walks

@@ -264,11 +264,9 @@ int launch_seeds(const Roots3Args &a, hipStream_t stream) {
     const size_t lds = S::lds_bytes(a.n0);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage3_seeds_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
     auto kern = sage3_seeds_kernel<FU, FI, HH1, HH2, HH3>;
-    static thread_local const void *configured = nullptr;
-    if (lds > 64 * 1024 && configured != (const void *)kern) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    if (lds > 64 * 1024) {
+        hipError_t e = gs::raise_lds_limit((const void *)kern, (int)kLdsMax);
         if (e != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage3_seeds_forward: cannot raise the LDS limit: %s", hipGetErrorString(e));
-        configured = (const void *)kern;
     }
     const long long tiles = (a.n_pairs + kSeedsPerWave - 1) / kSeedsPerWave;
     long long blocks = 2 * ((tiles + kSeedWaves - 1) / kSeedWaves);

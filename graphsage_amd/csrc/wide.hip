@@ -295,6 +295,16 @@ struct Producer {
     __device__ __forceinline__ void wait_last_chunk(Slice &s, int newer, bool ids) {
         static_assert(PP * CH <= 32, "one mask bit per load");
         static_assert(PP * CH + kIdLoads < 64, "vmcnt is a 6-bit count");
+        // Invariant behind the counts: between the loads this wait is for and the wait itself, this thread has
+        // issued exactly one begin() of the other slice -- whose last chunk is PP loads (a single child: the own
+        // rows) or PP * CH loads (children; slots past the count repeat the last child, so the number does not
+        // depend on it) -- and, when `ids`, one ids_issue() of kIdLoads loads, in that order or the reverse.
+        // The checking build (-DGS_WIDE_SAFE_WAITS, libgsage_safewait.so) waits for everything instead; a test
+        // compares the two builds bit for bit, so a miscount shows up as a difference.
+#ifdef GS_WIDE_SAFE_WAITS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (void)newer; (void)ids;
+#else
         if (!ids) {                                                // uniform
             if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * CH) : "memory");
@@ -302,6 +312,7 @@ struct Producer {
             if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP + kIdLoads) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * CH + kIdLoads) : "memory");
         }
+#endif
 #pragma unroll
         for (int p = 0; p < PP; ++p)
 #pragma unroll
@@ -437,9 +448,14 @@ struct Producer {
         const int n = sg.n_child;
         uint32_t *cdst = crow + parity * kWaveRows * a.max_child;
         const uint32_t fbn = BIG ? 1u : (uint32_t)sh.Fn * 4u, fbs = BIG ? 1u : (uint32_t)sh.Fs * 4u;
+#ifdef GS_WIDE_SAFE_WAITS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (void)newer;
+#else
         if (newer == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // uniform
         else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP * CH) : "memory");
+#endif
 #pragma unroll
         for (int i = 0; i < IDC; ++i) asm volatile("" : "+v"(cv[i]));                       // uses stay behind the wait
         asm volatile("" : "+v"(hv));
@@ -752,13 +768,9 @@ int gs::sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream) {
     // tables below 4 GB are addressed with 32-bit byte offsets
     const bool big = (unsigned long long)a.n_rows_self * Fs * 4ull >= (1ull << 32) - 1024 ||
                      (unsigned long long)a.n_rows_neigh * Fn * 4ull >= (1ull << 32) - 1024;
-    static const hipError_t attr = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes(kMaxChild));
-        if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes(kMaxChild));
-    }();
+    const void *kern = big ? reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, true>)
+                           : reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, false>);
+    const hipError_t attr = gs::raise_lds_limit(kern, (int)wide_lds_bytes(kMaxChild));
     if (attr != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage_fused_fwd: %s", hipGetErrorString(attr));
     static const int n_cu = [] {
         int dev = 0, n = 0;

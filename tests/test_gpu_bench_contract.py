@@ -35,3 +35,27 @@ def test_bench_line_has_the_agreed_fields(cuda):
     assert cpu['kind'] in ('port', 'reference') and cpu['cores'] >= 1 and cpu['value'] > 0 and cpu['sample']
     # the secondary timing: the training step (24/19-wide features run on padded copies), or the reason it was skipped
     assert 'skipped' in r['train_step'] or r['train_step']['value'] > 0
+
+
+def test_headline_line_carries_measured_traffic(cuda):
+    """The default workload (cfg 2): the roofline's traffic comes from the stored counter pass of the kernel
+    source that is running (a stale pass would print null), fractions stay below one, the CPU baseline names
+    its cores and the whole-step figure prices the bytes of the route taken."""
+    env = dict(os.environ, BENCH_WATCHDOG_S='270')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '10', '--warmup', '5', '--cpu-batches', '3',
+                          '--train-steps', '5'], capture_output=True, text=True, timeout=290, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r['config']['workload'].startswith('cfg2') and r['config']['batch_per_gpu'] == 4096 and r['dtype'] == 'f32'
+    roof = r['roofline']
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
+    assert roof['traffic'] is not None, "profiles/traffic.json holds no counter pass of the current sage2.hip"
+    assert 0.3 < roof['frac'] <= 1.0 and 0.3 < roof['cache_aware']['frac'] <= 1.0
+    assert 0.5 * roof['bytes_per_launch'] < roof['traffic'] < 1.5 * roof['bytes_per_launch']
+    assert roof['launches_timed'] >= 2 and roof['launch_us'] * 1e-3 <= r['ms_per_step'] * 1.05
+    assert abs(roof['achieved'] - roof['bytes_per_launch'] / roof['launch_us'] * 1e-3) < 1e-6 * roof['achieved']
+    assert r['cpu_baseline']['cores'] == 1 and r['cpu_baseline']['kind'] == 'port'
+    assert r['whole_step_gbps'] <= roof['achieved'] * 1.001 and r['layered_accounting']['note']
+    assert r['train_step']['value'] > 0 and r['forward_pipelined']['value'] > 0

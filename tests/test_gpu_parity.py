@@ -4,6 +4,8 @@ Integer work (sampling, regroup, gather) is compared bit for bit; floating-point
 work (neighbor mean, projection, embeddings, gradients) within 1e-5 relative to
 the float64 oracle, the tolerance the project states for fp32.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -616,6 +618,35 @@ def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_
             np.testing.assert_array_equal(save_s[start + sel].cpu().numpy(), ts[hid].astype(np.float32))
             close(save_m[start + sel], torch.from_numpy(xn.mean(1)), scale=1.0)
         start += nh
+
+
+def test_wide_kernel_wait_counts(cuda, tmp_path):
+    """The wide kernel's producers wait for their row loads by count (``s_waitcnt vmcnt(N)`` with N the number
+    of loads issued after the ones waited for).  A wrong count reads registers before their data arrives and
+    faults nothing.  libgsage_safewait.so is the same source with every such wait replaced by a wait for all
+    loads: both builds must produce the same bits over full and partial chunks, single children, zero rows,
+    several segments and saved copies."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    safe = os.path.join(ROOT, 'graphsage_amd', 'libgsage_safewait.so')
+    assert os.path.exists(safe), "build the checking library: make -C graphsage_amd/csrc safewait"
+    worker = os.path.join(ROOT, 'tests', 'wide_waits_worker.py')
+    res = {}
+    for name, lib in (('product', None), ('safe', safe)):
+        env = {k: v for k, v in os.environ.items() if k != 'GSAGE_LIB'}
+        if lib:
+            env['GSAGE_LIB'] = lib
+        out = str(tmp_path / (name + '.pt'))
+        r = subprocess.run([sys.executable, worker, '--out', out], env=env, capture_output=True, text=True, timeout=200, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert (lib or 'libgsage.so') in r.stdout
+        res[name] = torch.load(out, weights_only=True)
+    assert res['product'].keys() == res['safe'].keys() and len(res['product']) >= 10
+    for k in res['product']:
+        a, b = res['product'][k], res['safe'][k]
+        assert not torch.isnan(a).any(), k
+        assert torch.equal(a, b), "%s differs between the counted and the full waits" % k
 
 
 @pytest.mark.parametrize('ns,sizes,fu,fi,b', [([6, 4, 3], [32, 32, 32], 64, 64, 24), ([25, 10, 5], [32, 32, 32], 64, 64, 40),

@@ -7,7 +7,7 @@
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-template <int KIND>
+template <int KIND, int MK = 0>
 __global__ __launch_bounds__(512) void k(float *out, long long *cyc, int n_mfma, int n_valu, int swap, int prio) {
     const int wave = (threadIdx.x >> 6) ^ (swap ? 4 : 0);
     if (prio == 1 && wave >= 4) __builtin_amdgcn_s_setprio(3);
@@ -17,9 +17,19 @@ __global__ __launch_bounds__(512) void k(float *out, long long *cyc, int n_mfma,
         f32x4 acc[8];
         for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         float a = threadIdx.x * 0.001f, b = 1.0f + threadIdx.x * 0.002f;
-        for (int it = 0; it < n_mfma; ++it) {
+        if (MK == 0) {
+            for (int it = 0; it < n_mfma; ++it) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+            }
+        } else {                             // bf16 operands: v_mfma_f32_16x16x32_bf16, eight values per lane and operand
+            using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+            bf16x8 va, vb;
+            for (int i = 0; i < 8; ++i) { va[i] = (__bf16)(a + i); vb[i] = (__bf16)(b - i); }
+            for (int it = 0; it < n_mfma; ++it) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, vb, acc[i], 0, 0, 0);
+            }
         }
         float s = 0.f;
         for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -55,12 +65,12 @@ __global__ __launch_bounds__(512) void k(float *out, long long *cyc, int n_mfma,
     if (threadIdx.x == 0) cyc[blockIdx.x] = clock64() - t0;
 }
 
-template <int KIND>
+template <int KIND, int MK = 0>
 void run(const char *name, float *out, long long *cyc, int swap = 0, int prio = 0) {
     const int NM = 4096, NV = 4096;   // 32768 MFMA (x32 cycles = 1.05 M cycles), 32768 vector instructions per wave
     for (int mode = 0; mode < 3; ++mode) {
         const int nm = mode != 1 ? NM : 0, nv = mode != 0 ? NV : 0;
-        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(512), 0, 0, out, cyc, nm, nv, swap, prio);
+        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<KIND, MK>), dim3(256), dim3(512), 0, 0, out, cyc, nm, nv, swap, prio);
         hipDeviceSynchronize();
         static long long h[256 * 9];
         hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
@@ -82,5 +92,7 @@ int main() {
     run<0>("add prio-m", out, cyc, 0, 2);
     run<0>("add sw+prio-v", out, cyc, 1, 1);
     run<1>("v_pk_add_f32", out, cyc, 1, 1);
+    run<0, 1>("bf16 + add", out, cyc);
+    run<0, 1>("bf16 + add sw", out, cyc, 1, 0);
     return 0;
 }
