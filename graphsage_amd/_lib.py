@@ -59,6 +59,10 @@ SIGNATURES['gs_sage_fused_supported'] = (_i32, [_i32, _i32, _i32, _i32])
 SIGNATURES['gs_sage_fused_fwd'] = (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i64,
                                           _c.POINTER(FusedSegment), _i32, _vp, _vp, _vp, _i32, _i32, _i32,
                                           _vp, _vp, _vp, _vp])
+SIGNATURES['gs_sage_fused_workspace_bytes'] = (_sz, [_i32, _i32, _i32, _i32])
+SIGNATURES['gs_sage_fused_fwd_ws'] = (_i32, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i64,
+                                             _c.POINTER(FusedSegment), _i32, _vp, _vp, _vp, _i32, _i32, _i32,
+                                             _vp, _vp, _vp, _vp, _sz, _vp])
 
 
 

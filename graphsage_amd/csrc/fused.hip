@@ -423,7 +423,25 @@ static int fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_
                      const float *W_self, const float *W_neigh, const float *bias,
                      int H, int act, int normalize,
                      float *out, float *save_self, float *save_mean,
-                     const gs_fused_sampling *sampling, const gs_fused_draw *draws, void *stream);
+                     const gs_fused_sampling *sampling, const gs_fused_draw *draws, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
+extern "C" size_t gs_sage_fused_workspace_bytes(int Fs, int Fn, int H, int max_child) {
+    if (narrow_supported(Fs, Fn, H, max_child) || !gs::sage_wide_supported(Fs, Fn, H, max_child)) return 0;
+    return gs::sage_wide_workspace_bytes(Fs, Fn, H);
+}
+
+extern "C" int gs_sage_fused_fwd_ws(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
+                                    const float *feat_neigh, int64_t n_rows_neigh, int Fn, int64_t off_neigh,
+                                    const gs_fused_segment *segs, int n_segs,
+                                    const float *W_self, const float *W_neigh, const float *bias,
+                                    int H, int act, int normalize,
+                                    float *out, float *save_self, float *save_mean,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
+    return fused_fwd(feat_self, n_rows_self, Fs, off_self, feat_neigh, n_rows_neigh, Fn, off_neigh, segs, n_segs,
+                     W_self, W_neigh, bias, H, act, normalize, out, save_self, save_mean, nullptr, nullptr,
+                     workspace, workspace_bytes, stream);
+}
 
 extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
                                  const float *feat_neigh, int64_t n_rows_neigh, int Fn, int64_t off_neigh,
@@ -432,7 +450,7 @@ extern "C" int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, in
                                  int H, int act, int normalize,
                                  float *out, float *save_self, float *save_mean, void *stream) {
     return fused_fwd(feat_self, n_rows_self, Fs, off_self, feat_neigh, n_rows_neigh, Fn, off_neigh, segs, n_segs,
-                     W_self, W_neigh, bias, H, act, normalize, out, save_self, save_mean, nullptr, nullptr, stream);
+                     W_self, W_neigh, bias, H, act, normalize, out, save_self, save_mean, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int gs_sage_fused_sampled_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
@@ -444,7 +462,7 @@ extern "C" int gs_sage_fused_sampled_fwd(const float *feat_self, int64_t n_rows_
                                          const gs_fused_sampling *sampling, const gs_fused_draw *draws, void *stream) {
     if (!sampling || !draws) return gs::fail(GS_EINVAL, "gs_sage_fused_sampled_fwd: sampling and draws must be given");
     return fused_fwd(feat_self, n_rows_self, Fs, off_self, feat_neigh, n_rows_neigh, Fn, off_neigh, segs, n_segs,
-                     W_self, W_neigh, bias, H, act, normalize, out, save_self, save_mean, sampling, draws, stream);
+                     W_self, W_neigh, bias, H, act, normalize, out, save_self, save_mean, sampling, draws, nullptr, 0, stream);
 }
 
 static int fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
@@ -453,7 +471,8 @@ static int fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_
                      const float *W_self, const float *W_neigh, const float *bias,
                      int H, int act, int normalize,
                      float *out, float *save_self, float *save_mean,
-                     const gs_fused_sampling *sampling, const gs_fused_draw *draws, void *stream) {
+                     const gs_fused_sampling *sampling, const gs_fused_draw *draws, void *workspace, size_t workspace_bytes,
+                     void *stream) {
     if (n_segs < 0 || n_segs > kMaxSegs) return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: n_segs=%d outside [0,%d]", n_segs, kMaxSegs);
     if (act != GS_ACT_LINEAR && act != GS_ACT_RELU) return gs::fail(GS_EINVAL, "gs_sage_fused_fwd: unknown activation %d", act);
     FusedArgs a{};
@@ -527,6 +546,13 @@ static int fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64_
     if (!narrow_supported(Fs, Fn, H, max_child)) {                                            // wide layers: wide.hip
         if (any_drawn) return gs::fail(GS_ELIMIT, "gs_sage_fused_sampled_fwd: the wide-layer kernel reads child ids; "
                                                   "run gs_sample for every hop and use gs_sage_fused_fwd");
+        if (workspace) {
+            const size_t need = gs::sage_wide_workspace_bytes(Fs, Fn, H);
+            if (workspace_bytes < need)
+                return gs::fail(GS_EINVAL, "gs_sage_fused_fwd_ws: workspace of %zu bytes, %zu needed (gs_sage_fused_workspace_bytes)",
+                                workspace_bytes, need);
+            a.split_ws = workspace;
+        }
         return gs::sage_wide_fwd(a, Fs, Fn, H, s);
     }
     const int hh = H / 2;

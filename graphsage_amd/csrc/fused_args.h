@@ -48,10 +48,12 @@ struct FusedArgs {
     long long n_tiles;
     int act, normalize, max_child;
     Draws draws;               // used when some segment has hop >= 0
+    void *split_ws;            // wide layers: workspace of the bf16-piece form of the product (NULL: the fp32 form)
 };
 
 // Wide layers (wide.hip).  `a.seg[].tile0` / `a.n_tiles` are recomputed for 128-head tiles.
 bool sage_wide_supported(int Fs, int Fn, int H, int max_child);
 int sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream);
+size_t sage_wide_workspace_bytes(int Fs, int Fn, int H);
 
 }  // namespace gs

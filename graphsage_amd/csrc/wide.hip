@@ -40,6 +40,18 @@
 // which is what absorbs the spread of the row loads' latency.  Every wait is a bounded spin (a
 // block whose count never arrives writes NaN to its first output element instead of hanging).
 //
+// Two forms of the product.  Without a workspace the operands stay fp32 and the consumers run
+// v_mfma_f32_16x16x4_f32.  That instruction executes on the SIMD's vector ALU: while a wave streams it, no other
+// wave of that SIMD issues a vector instruction (tools/micro/mfma_valu.cpp: time of both = sum of the times), so
+// the producers' adds and the matrix product take turns and the kernel runs at about half of either's rate.
+// With a workspace (SPLIT) every fp32 operand is cut into three bf16 pieces whose sum is the operand exactly
+// (8 + 8 + 8 significand bits, by truncation), the nine piece products -- each exact in fp32 -- are accumulated in
+// fp32 by v_mfma_f32_16x16x32_bf16, which runs on the matrix cores beside the vector ALU at sixteen times the
+// rate: 9/16 of the matrix time, overlapped with the producers.  The result is the fp32 product with the same
+// (or smaller) rounding error; only the order of the additions differs.  The weights are cut once per call by
+// a small kernel into the workspace (transposed, so that a lane's eight k values are 16 consecutive bytes), the
+// gathered operand by the producers as they write a stage.
+//
 // Neither the gathered rows nor the means go through memory; when the caller asks for copies
 // (save_self / save_mean, for a backward pass) the producers also write each
 // finished piece there.
@@ -72,11 +84,14 @@ using gs::kMaxSegs;
 
 constexpr int WM = 128, WN = 128, WK = 32;
 constexpr int W_TILE = WM * WK;                 // floats of one operand slice (A or B): 16 KB
+constexpr int W_PLANE_B = WM * WK * 2;          // SPLIT: bytes of one bf16 plane of a slice (128 rows x 64 B): 8 KB
+constexpr int W_TILE_S = 3 * W_PLANE_B / 4;     // SPLIT: floats of a stage (three planes): 24 KB
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int EP_LD = 68;                       // row stride of the epilogue patch (lane quarters 16 banks apart)
 constexpr int kConsumerThreads = 256;           // four waves, 2 x 2 quarters of the tile
 constexpr int kConsumerWaves = 4, kProducerWaves = 8;
 constexpr int kMaxChild = 32;
-constexpr int kStages = 4;                      // LDS stages of the operand slice
+constexpr int kMaxStages = 8;                   // LDS stages of the operand slice, at most; a launch takes what LDS holds
 constexpr int kWaveRows = WM / kProducerWaves;  // heads of a tile whose rows one producer wave fetches: 16
 constexpr int kSpinLimit = 1 << 22;             // polls before a wait gives up (each tens of cycles or more)
 
@@ -171,7 +186,18 @@ __device__ __forceinline__ void advance(Cursor &c, const Shape &sh, const FusedA
 // its row index (BIG), kNoKey for "counts as zeros".
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 
-template <int NPT, int CH, bool BIG>
+// x = hi + mid + lo exactly, each piece a bf16 (the top half of an fp32 word): truncation keeps every
+// difference exact, 24 significand bits = 3 x 8.  (Results below the bf16 normal range lose their lowest piece.)
+__device__ __forceinline__ void split3(float x, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    hi = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xFFFF0000u;
+    lo = __float_as_uint(r1 - __uint_as_float(mid));
+}
+// the top halves of two fp32 words as one register: lo half from a, hi half from b
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+template <int NPT, int CH, bool BIG, bool SPLIT>
 struct Producer {
     static_assert(NPT == 64 * kProducerWaves, "eight producer waves: a wave fetches rows 8w .. 8w+7 and 64+8w .. 64+8w+7 of a tile");
     static constexpr int PP = 1024 / NPT;            // 16-byte pieces of A per thread and slice: 2
@@ -213,6 +239,10 @@ struct Producer {
             // fragment block (k half, 16-row block), slot (k quad, row) with the row rotated by 2 * (k quad):
             // this write and the fragment read both touch sixteen different 16-byte bank groups
             a_dst[p] = ((a_kq >> 2) * 8 + (row >> 4)) * 256 + ((a_kq & 3) * 16 + (((row & 15) + 2 * a_kq) & 15)) * 4;
+            // SPLIT: a plane is [128 rows][32 k] bf16, 64 bytes per row; a lane of the product reads the 16 bytes
+            // of k = 8q .. 8q+7, so the four 16-byte pieces of a row are permuted by bits 2-3 of the row (sixteen
+            // consecutive rows then cover all banks); this thread's four k are half of such a piece.  In bytes.
+            if (SPLIT) a_dst[p] = row * 64 + (((a_kq >> 1) ^ ((row >> 2) & 3)) * 16) + (a_kq & 1) * 8;
         }
     }
 
@@ -395,7 +425,7 @@ struct Producer {
     // the slice in flight: last chunk added, mean taken, this thread's pieces written to LDS stage `buf`.
     // `newer`, `ids`: what this thread issued after this slice's loads (see wait_last_chunk).
     __device__ __forceinline__ void finish(Slice &s, int buf, int newer, bool ids) {
-        float *As = st + buf * W_TILE;
+        float *As = st + buf * (SPLIT ? W_TILE_S : W_TILE);
         wait_last_chunk(s, newer, ids);
         accumulate(s);
         if (s.inv != 1.0f) {                                       // uniform
@@ -403,8 +433,21 @@ struct Producer {
 #pragma unroll
             for (int p = 0; p < PP; ++p) s.acc[p] *= s.inv;
         }
+        if (SPLIT) {
+            char *Ab = reinterpret_cast<char *>(As);
 #pragma unroll
-        for (int p = 0; p < PP; ++p) *reinterpret_cast<f32x4 *>(As + a_dst[p]) = s.acc[p];
+            for (int p = 0; p < PP; ++p) {
+                uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3(s.acc[p][e], hi[e], mid[e], lo[e]);
+                *reinterpret_cast<uint2 *>(Ab + a_dst[p]) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
+                *reinterpret_cast<uint2 *>(Ab + W_PLANE_B + a_dst[p]) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
+                *reinterpret_cast<uint2 *>(Ab + 2 * W_PLANE_B + a_dst[p]) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < PP; ++p) *reinterpret_cast<f32x4 *>(As + a_dst[p]) = s.acc[p];
+        }
         if (s.save_base) {                                         // uniform
 #pragma unroll
             for (int p = 0; p < PP; ++p)
@@ -500,15 +543,18 @@ struct Producer {
 };
 
 // ---- kernel ---------------------------------------------------------------------
-template <int NPT, int CH, bool BIG>
+template <int NPT, int CH, bool BIG, bool SPLIT>
 __global__ __launch_bounds__(kConsumerThreads + NPT)
-void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int HH) {
+void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int HH, const int kStages) {
     extern __shared__ __align__(16) float w_smem[];
     float *st = w_smem;                                            // kStages operand slices
-    float *ep = st + kStages * W_TILE;                             // four epilogue patches [16][EP_LD]
-    uint32_t *full = reinterpret_cast<uint32_t *>(ep + 4 * 16 * EP_LD);  // [kStages] producer parts written, ever
-    uint32_t *empty = full + kStages;                              // [kStages] consumer reads issued, ever
-    uint32_t *hrow = empty + kStages;                              // [8 waves][2][16] keys of the own rows of a tile
+    // after them: the four epilogue patches [16][EP_LD] (fp32 form) or the two buffers of the weight pieces (SPLIT)
+    float *ep = st + kStages * (SPLIT ? W_TILE_S : W_TILE);
+    uint32_t *full = reinterpret_cast<uint32_t *>(ep + (SPLIT ? 2 * W_TILE_S : 4 * 16 * EP_LD));  // [kMaxStages] producer parts written, ever
+    uint32_t *empty = full + kMaxStages;                           // [kMaxStages] consumer reads issued, ever
+    uint32_t *bfull = empty + kMaxStages;                          // SPLIT [2]: consumer waves whose part of a weight buffer has landed, ever
+    uint32_t *bempty = bfull + 2;                                  // SPLIT [2]: consumer waves that have read a weight buffer, ever
+    uint32_t *hrow = bempty + 2;                                   // [8 waves][2][16] keys of the own rows of a tile
     uint32_t *crow = hrow + kProducerWaves * 2 * kWaveRows;        // [8 waves][2][16 * max_child] child rows of a tile
 
     const int tid = threadIdx.x;
@@ -522,12 +568,12 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     const int H = 2 * HH;
     bool stalled = false;                                          // some wait of this wave gave up
 
-    if (tid < 2 * kStages) full[tid] = 0u;
+    if (tid < 2 * kMaxStages + 4) full[tid] = 0u;
     block_sync();                                                  // the only block barrier
 
     if (tid >= kConsumerThreads) {
-        Producer<NPT, CH, BIG> pr(a, sh, st, hrow, crow, tid - kConsumerThreads);
-        typename Producer<NPT, CH, BIG>::Slice s0, s1;             // slices of even / odd index
+        Producer<NPT, CH, BIG, SPLIT> pr(a, sh, st, hrow, crow, tid - kConsumerThreads);
+        typename Producer<NPT, CH, BIG, SPLIT>::Slice s0, s1;      // slices of even / odd index
         Cursor cl{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0};      // next slice to load
         enter_tile(cl, a);
         Cursor cc = cl;                                            // slice that goes to LDS next
@@ -640,6 +686,168 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         }
     };
 
+    if constexpr (SPLIT) {
+        // ---- consumers, bf16 pieces on v_mfma_f32_16x16x32_bf16 ----
+        // Lane (r, q) of the A operand holds row r, k = 8q .. 8q+7 of a 16 x 32 tile: one 16-byte LDS read per
+        // (row tile, plane), all twelve of a slice resident.  The B operand is column r, the same k: 16 bytes of a
+        // transposed weight plane, column 4r + j for column tile j (so that a lane's four accumulators of a row
+        // tile are four consecutive columns).  A weight slice -- 128 columns x 32 k x 3 planes = 24 KB, the same
+        // for every tile -- comes from the workspace (L2) through LDS: loads queue behind the gathers in this
+        // compute unit's memory pipeline and take microseconds, far longer than registers could cover, so each
+        // consumer wave copies a quarter of the NEXT slice's weights into the other of two LDS buffers with
+        // loads that write LDS directly (no registers), a whole slice ahead.  The copy's image is the read
+        // order: chunk (column half, column tile, plane) = 64 lanes x 16 bytes, so a lane reads back exactly the
+        // bytes its namesake lane fetched, free of bank conflicts.  Two counters per buffer order the four
+        // waves: parts landed (before anyone reads), readers done (before anyone overwrites).
+        const int rowsw = (r >> 2) & 3;
+        const int a_lane = (wave_m * 64 + r) * 64 + ((q ^ rowsw) * 16);               // bytes inside a plane
+        const uint16_t *wsp = reinterpret_cast<const uint16_t *>(a.split_ws);
+        const unsigned long long ws_side[2] = {reinterpret_cast<unsigned long long>(wsp),
+                                               reinterpret_cast<unsigned long long>(wsp + (size_t)3 * HH * Fs)};   // planes of W_self, of W_neigh
+        const char *bring = reinterpret_cast<const char *>(ep);                      // two buffers of kBSlice bytes
+        constexpr int kBSlice = 3 * W_PLANE_B;                                       // 24 KB
+        const uint32_t bring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(ep));
+        // this wave's six chunks of a slice: column half wave >> 1, column tiles 2 (wave & 1) and + 1, planes 0 .. 2
+        const int cp_wn = wave >> 1, cp_j0 = 2 * (wave & 1);
+        auto issue_b = [&](const Cursor &cur, int buf) {
+            const int F_ = cur.side ? Fn : Fs;
+            // [plane][column][k]: 16 bytes at (column, 8q)
+            const unsigned long long src0 = ws_side[cur.side] +
+                2ull * ((unsigned long long)(cur.ct * WN + cp_wn * 64 + 4 * r + cp_j0) * F_ + cur.ks * WK + 8 * q);
+            const unsigned long long plane = 2ull * HH * F_, col = 2ull * F_;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const unsigned long long src = src0 + (t / 3) * col + (t % 3) * plane;
+                const uint32_t dst = bring_lds + buf * kBSlice + ((cp_wn * 4 + cp_j0 + t / 3) * 3 + t % 3) * 1024;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        };
+        bf16x8 aP[3][4], bA[3], bB[3];
+#define WS_READ_B(dst_, buf_, j_)                                                                    \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                             \
+            dst_[pl] = *reinterpret_cast<const bf16x8 *>(bring + (buf_) * kBSlice + ((wave_n * 4 + (j_)) * 3 + pl) * 1024 + lane * 16);
+        // nine piece products per (row tile, column tile); the smallest first
+#define WS_MFMA(j_, b_)                                                                              \
+        _Pragma("unroll") for (int pa = 2; pa >= 0; --pa)                                            \
+            _Pragma("unroll") for (int pb = 2; pb >= 0; --pb)                                        \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                    acc[i][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aP[pa][i], b_[pb], acc[i][j_], 0, 0, 0);
+
+        // bias, activation and store of this wave's 64 x 64 quarter straight from the accumulators: register e of
+        // accumulator (i, j) is row 16i + 4q + e, column 4r + j, so the four accumulators of a row tile give a
+        // lane four consecutive columns: one 16-byte store per (row tile, e), 256 bytes of each of four rows
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        auto load_bias = [&](const Cursor &d) {
+            if (a.bias) {
+                const int colbase = d.side * HH + d.ct * WN + wave_n * 64;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = a.bias[colbase + 4 * r + j];
+            }
+        };
+        auto store_quarter = [&](const Cursor &d) {
+            const Seg &sg = a.seg[find_seg(a, d.tile)];
+            const long long p0 = (long long)(d.tile - (int)sg.tile0) * WM;
+            const int np = (int)min((long long)WM, sg.n_heads - p0);
+            const int colbase = d.side * HH + d.ct * WN + wave_n * 64;
+            float *__restrict__ outp = a.out + (sg.out_row0 + p0 + wave_m * 64) * H + colbase;
+            const uint32_t lane_off = (uint32_t)(4 * q * H + r * 4);
+            const int row_q = wave_m * 64 + 4 * q;
+            const bool relu = a.act == GS_ACT_RELU;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x4 v = {acc[i][0][e] + bv[0], acc[i][1][e] + bv[1], acc[i][2][e] + bv[2], acc[i][3][e] + bv[3]};
+                    if (relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    if (row_q + i * 16 + e < np)
+                        *reinterpret_cast<f32x4 *>(outp + (long long)(i * 16 + e) * H + lane_off) = v;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+
+        Cursor c{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0};
+        Cursor cn = c;                                              // the slice after c (the last one stays put)
+        issue_b(c, 0);
+        if (T > 1) advance(cn, sh, a);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flag_add(bfull);
+        if (!flag_wait(full, kProducerWaves, flag_peek(full))) stalled = true;
+        int stage = 0;
+        uint32_t use = 1;
+        STAMP_VARS(t_full[2] = {0, 0}, t_epi = 0, t_b = 0, t_begin = clock64())
+        for (int g = 0; g < T; ++g) {
+            const char *S = reinterpret_cast<const char *>(st + stage * W_TILE_S) + a_lane;
+            const int buf = g & 1, nbuf = buf ^ 1;
+            int nstage = stage + 1;
+            uint32_t nuse = use;
+            if (nstage == kStages) { nstage = 0; ++nuse; }
+            // the next slice's weights into the other buffer, once its readers (slice g - 1) are done
+            STAMP(t0b)
+            if (g + 1 < T) {
+                const uint32_t reads = (uint32_t)((g + 1) >> 1);                    // earlier slices that used it
+                if (reads && !flag_wait(bempty + nbuf, reads * kConsumerWaves, flag_peek(bempty + nbuf))) stalled = true;
+                issue_b(cn, nbuf);
+            }
+            if (c.ks == 0) load_bias(c);
+            // this slice's weights: all four parts landed
+            if (!flag_wait(bfull + buf, (uint32_t)((g >> 1) + 1) * kConsumerWaves, flag_peek(bfull + buf))) stalled = true;
+            STAMP_ADD(t_b, t0b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aP[pl][i] = *reinterpret_cast<const bf16x8 *>(S + pl * W_PLANE_B + i * 1024);
+            flag_add(empty + stage);                               // all reads of the stage are issued
+            const uint32_t seen = flag_peek(full + nstage);
+            WS_READ_B(bA, buf, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            WS_READ_B(bB, buf, 1)
+            WS_MFMA(0, bA)
+            __builtin_amdgcn_sched_barrier(0);
+            WS_READ_B(bA, buf, 2)
+            WS_MFMA(1, bB)
+            __builtin_amdgcn_sched_barrier(0);
+            WS_READ_B(bB, buf, 3)
+            flag_add(bempty + buf);                                // all reads of the weight buffer are issued
+            WS_MFMA(2, bA)
+            __builtin_amdgcn_sched_barrier(0);
+            WS_MFMA(3, bB)
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < T) {                                       // this wave's part of the next slice's weights has landed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                flag_add(bfull + nbuf);
+            }
+            if (c.ks + 1 == (c.side ? sh.nn : sh.ns)) {
+                STAMP(t0e)
+                store_quarter(c);
+                STAMP_ADD(t_epi, t0e)
+            }
+            STAMP(t0f)
+            if (g + 1 < T && !flag_wait(full + nstage, nuse * kProducerWaves, seen)) stalled = true;
+            STAMP_ADD(t_full[cn.side], t0f)
+            advance(c, sh, a);
+            if (g + 2 < T) advance(cn, sh, a);
+            stage = nstage;
+            use = nuse;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stalled && lane == 0) a.out[0] = __builtin_nanf("");
+#ifdef GS_WIDE_STAMP
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && wave == 1)
+            printf("blk %d consumer (pieces): total %lld  wait-full %lld/%lld  weights %lld  epilogue %lld  slices %d\n", (int)blockIdx.x,
+                   clock64() - t_begin, t_full[0], t_full[1], t_b, t_epi, T);
+#endif
+#undef WS_READ_B
+#undef WS_MFMA
+        return;
+    }
+
     // a##S##i: row tile i, element st = k step (k = 16 half + 4q + st); b##S##st: k step st, element j =
     // column tile (columns 4r + j)
     f32x4 aX0, aX1, aX2, aX3, aY0, aY1, aY2, aY3;
@@ -740,9 +948,34 @@ void l2norm_inplace_kernel(float *x, int64_t M, int H) {
 
 constexpr int kProducerThreads = 512, kChunk = 5;
 
-inline size_t wide_lds_bytes(int max_child) {
-    return (size_t)(kStages * W_TILE + 4 * 16 * EP_LD) * sizeof(float) +
-           (size_t)(2 * kStages + 2 * WM + 2 * WM * max_child) * sizeof(int32_t);
+inline size_t wide_lds_bytes(int max_child, bool split, int stages) {
+    return (size_t)(stages * (split ? W_TILE_S : W_TILE) + (split ? 2 * W_TILE_S : 4 * 16 * EP_LD)) * sizeof(float) +
+           (size_t)(2 * kMaxStages + 4 + 2 * WM + 2 * WM * max_child) * sizeof(int32_t);
+}
+constexpr size_t kWideLdsMax = 160 * 1024;
+// fp32 form: four stages.  SPLIT: as many as fit beside the two weight buffers and the id patches (the stages are
+// how far the producers run ahead of the product)
+inline int wide_stages(int max_child, bool split) {
+    if (!split) return 4;
+    int n = 2;
+    while (n < kMaxStages && wide_lds_bytes(max_child, true, n + 1) <= kWideLdsMax) ++n;
+    return n;
+}
+
+// W [F][HH] fp32 -> three bf16 planes [plane][HH][F] (transposed: a lane of the product reads eight consecutive k
+// of one column), plane 0 the leading piece.  One thread per element; the reads are coalesced, the 2-byte writes
+// are not (a few hundred KB once per call).
+__global__ __launch_bounds__(256)
+void wide_split_weights_kernel(const float *__restrict__ W, int F, int HH, uint16_t *__restrict__ planes) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)F * HH) return;
+    const int k = (int)(idx / HH), n = (int)(idx % HH);
+    uint32_t hi, mid, lo;
+    split3(W[idx], hi, mid, lo);
+    const size_t at = (size_t)n * F + k, plane = (size_t)HH * F;
+    planes[at] = (uint16_t)(hi >> 16);
+    planes[plane + at] = (uint16_t)(mid >> 16);
+    planes[2 * plane + at] = (uint16_t)(lo >> 16);
 }
 
 }  // namespace
@@ -751,6 +984,10 @@ bool gs::sage_wide_supported(int Fs, int Fn, int H, int max_child) {
     const int hh = H / 2;
     return H > 0 && H % 2 == 0 && hh % WN == 0 && Fs >= 2 * WK && Fn >= 2 * WK && Fs % WK == 0 && Fn % WK == 0 &&
            max_child >= 1 && max_child <= kMaxChild;
+}
+
+size_t gs::sage_wide_workspace_bytes(int Fs, int Fn, int H) {
+    return (size_t)3 * (H / 2) * ((size_t)Fs + Fn) * sizeof(uint16_t);
 }
 
 int gs::sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream) {
@@ -768,9 +1005,12 @@ int gs::sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream) {
     // tables below 4 GB are addressed with 32-bit byte offsets
     const bool big = (unsigned long long)a.n_rows_self * Fs * 4ull >= (1ull << 32) - 1024 ||
                      (unsigned long long)a.n_rows_neigh * Fn * 4ull >= (1ull << 32) - 1024;
-    const void *kern = big ? reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, true>)
-                           : reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, false>);
-    const hipError_t attr = gs::raise_lds_limit(kern, (int)wide_lds_bytes(kMaxChild));
+    const bool split = a.split_ws != nullptr;
+    const void *kern = split ? (big ? reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, true, true>)
+                                    : reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, false, true>))
+                             : (big ? reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, true, false>)
+                                    : reinterpret_cast<const void *>(sage_wide_kernel<kProducerThreads, kChunk, false, false>));
+    const hipError_t attr = gs::raise_lds_limit(kern, (int)kWideLdsMax);
     if (attr != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage_fused_fwd: %s", hipGetErrorString(attr));
     static const int n_cu = [] {
         int dev = 0, n = 0;
@@ -779,10 +1019,24 @@ int gs::sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream) {
     }();
     const long long blocks = tiles < n_cu ? tiles : n_cu;          // one block per CU (LDS), tiles dealt round-robin
     const dim3 grid((unsigned)blocks), block(kConsumerThreads + kProducerThreads);
-    if (big)
-        gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, true>, grid, block, wide_lds_bytes(a.max_child), stream, a, Fs, Fn, H / 2);
+    const int stages = wide_stages(a.max_child, split);
+    const size_t lds = wide_lds_bytes(a.max_child, split, stages);
+    if (split) {
+        if (reinterpret_cast<uintptr_t>(a.split_ws) & 15)
+            return gs::fail(GS_EINVAL, "gs_sage_fused_fwd_ws: the workspace must be 16-byte aligned");
+        uint16_t *ws = static_cast<uint16_t *>(a.split_ws);
+        const int hh = H / 2;
+        hipLaunchKernelGGL(wide_split_weights_kernel, dim3((unsigned)(((long long)Fs * hh + 255) / 256)), dim3(256), 0, stream, a.W_self, Fs, hh, ws);
+        hipLaunchKernelGGL(wide_split_weights_kernel, dim3((unsigned)(((long long)Fn * hh + 255) / 256)), dim3(256), 0, stream, a.W_neigh, Fn, hh,
+                           ws + (size_t)3 * hh * Fs);
+        if (big)
+            gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, true, true>, grid, block, lds, stream, a, Fs, Fn, hh, stages);
+        else
+            gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, false, true>, grid, block, lds, stream, a, Fs, Fn, hh, stages);
+    } else if (big)
+        gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, true, false>, grid, block, lds, stream, a, Fs, Fn, H / 2, stages);
     else
-        gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, false>, grid, block, wide_lds_bytes(a.max_child), stream, a, Fs, Fn, H / 2);
+        gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, false, false>, grid, block, lds, stream, a, Fs, Fn, H / 2, stages);
     int rc = gs::check_launch("gs_sage_fused_fwd");
     if (rc != GS_OK || !a.normalize) return rc;
     long long nb = (rows + 3) / 4;

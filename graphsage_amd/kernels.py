@@ -6,6 +6,7 @@ shape it does not expect faults the GPU), then passes raw pointers and the
 current HIP stream to ``libgsage.so``.  Nothing in this file computes.
 """
 import ctypes
+import os
 
 import torch
 
@@ -573,7 +574,10 @@ class FusedLayerCall:
     of a step are arguments of ``run``."""
 
     def __init__(self, feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_neigh, bias, act,
-                 normalize, out, save_self=None, save_mean=None, sampling=None):
+                 normalize, out, save_self=None, save_mean=None, sampling=None, exact_pieces=None):
+        """``exact_pieces``: wide layers only.  True / None (default): the call owns a workspace and the product
+        runs on bf16 pieces of the fp32 operands (``gs_sage_fused_fwd_ws``); False: the fp32 matrix instruction.
+        The environment variable GSAGE_WIDE_F32=1 makes False the default."""
         lib = load()
         _dev(feat_self, torch.float32, 'feat_self', 2)
         _dev(feat_neigh, torch.float32, 'feat_neigh', 2)
@@ -651,6 +655,12 @@ class FusedLayerCall:
             self._sampling = sampling
             self._tape_len = int(sampling['tape_len'])
             self._keep += [sampling['indptr'], sampling['indices'], sampling['err_flag']]
+        if exact_pieces is None:
+            exact_pieces = not os.environ.get('GSAGE_WIDE_F32')
+        self._workspace = None
+        ws_bytes = lib.gs_sage_fused_workspace_bytes(fs, fn, 2 * hh, max_child) if exact_pieces and sampling is None else 0
+        if ws_bytes:
+            self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=feat_self.device)
         self._head = (ptr(feat_self), feat_self.shape[0], fs, int(off_self), ptr(feat_neigh), feat_neigh.shape[0],
                       fn, int(off_neigh), arr, len(segments))
         self._tail = (2 * hh, ACT[act], int(bool(normalize)), ptr(out), ptr(save_self), ptr(save_mean))
@@ -673,7 +683,11 @@ class FusedLayerCall:
         if self._epoch != _storage_epoch:
             self._read_weight_addresses()
         if self._sampling is None:
-            check(self._lib.gs_sage_fused_fwd(*self._args, stream_handle()), 'gs_sage_fused_fwd')
+            if self._workspace is not None:
+                check(self._lib.gs_sage_fused_fwd_ws(*self._args, self._workspace.data_ptr(), self._workspace.numel(),
+                                                     stream_handle()), 'gs_sage_fused_fwd_ws')
+            else:
+                check(self._lib.gs_sage_fused_fwd(*self._args, stream_handle()), 'gs_sage_fused_fwd')
             return self.out
         sp = self._sampling
         if walk_ids is not None:
@@ -693,13 +707,13 @@ class FusedLayerCall:
 
 
 def sage_fused(feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_neigh, bias, act,
-               normalize=False, out=None, save_self=None, save_mean=None):
-    """One aggregator layer in one kernel; see include/gsage.h: gs_sage_fused_fwd."""
+               normalize=False, out=None, save_self=None, save_mean=None, exact_pieces=None):
+    """One aggregator layer in one kernel; see include/gsage.h: gs_sage_fused_fwd / gs_sage_fused_fwd_ws."""
     rows = sum(int(sg['n_heads']) for sg in segments)
     if out is None:
         out = torch.empty((rows, 2 * w_self.shape[1]), dtype=torch.float32, device=feat_self.device)
     return FusedLayerCall(feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_neigh, bias, act,
-                          normalize, out, save_self, save_mean).run()
+                          normalize, out, save_self, save_mean, exact_pieces=exact_pieces).run()
 
 
 def sage2_supported(fu, fi, h1, h2, n0, n1):

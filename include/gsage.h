@@ -326,6 +326,28 @@ int gs_sage_fused_fwd(const float *feat_self, int64_t n_rows_self, int Fs, int64
                       float *out, float *save_self, float *save_mean, void *stream);
 
 /*
+ * gs_sage_fused_fwd with a device workspace, for wide layers (utils.py:109-119, the two matrix products).  The
+ * fp32 matrix instruction of this part runs on the vector ALU, so in the form without workspace the product and
+ * the neighbor sums of one compute unit take turns.  With a workspace every fp32 operand is cut into three bf16
+ * pieces that add up to it exactly (8 + 8 + 8 significand bits); the nine piece products are exact in fp32 and
+ * are accumulated in fp32 on the matrix cores, beside the vector work.  The result is the fp32 product up to
+ * the order of its additions: same tolerance against the float64 restatement as the form without workspace.
+ *   gs_sage_fused_workspace_bytes  bytes of workspace this shape uses: 3 * (H/2) * (Fs + Fn) * 2 for wide
+ *                                  layers, 0 where the narrow kernel applies (the workspace is then ignored)
+ *   workspace                      device memory, 16-byte aligned, at least that many bytes; overwritten by
+ *                                  every call (the cut weights), so calls in flight at once need one each.
+ *                                  NULL: exactly gs_sage_fused_fwd.
+ */
+size_t gs_sage_fused_workspace_bytes(int Fs, int Fn, int H, int max_child);
+int gs_sage_fused_fwd_ws(const float *feat_self, int64_t n_rows_self, int Fs, int64_t off_self,
+                         const float *feat_neigh, int64_t n_rows_neigh, int Fn, int64_t off_neigh,
+                         const gs_fused_segment *segs, int n_segs,
+                         const float *W_self, const float *W_neigh, const float *bias,
+                         int H, int act, int normalize,
+                         float *out, float *save_self, float *save_mean,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * gs_sage_fused_fwd with the children of some segments DRAWN inside the kernel
  * instead of read from child_ids: the deepest hop of a walk holds most of its
  * samples (1250 of 1525 for fan-outs 25/10/5), and drawing them where their

@@ -179,6 +179,13 @@ int main() {
     sg[0].n_child = 4000;                                          // more children than a block's LDS holds
     REFUSED(GS_ELIMIT, gs_sage_fused_fwd(f, 10, 64, 0, f, 10, 64, 0, sg, 2, f, f, f, 32, GS_ACT_RELU, 0, f, nullptr, nullptr, nullptr));
     sg[0].n_child = 5;
+    // the workspace form: sizes, and a workspace that is too small
+    EXPECT(gs_sage_fused_workspace_bytes(64, 64, 32, 25) == 0);                    // narrow layers use none
+    EXPECT(gs_sage_fused_workspace_bytes(256, 256, 256, 5) == (size_t)3 * 128 * 512 * 2);
+    EXPECT(gs_sage_fused_workspace_bytes(256, 256, 256, 33) == 0);                 // outside every kernel's range
+    ACCEPTED(gs_sage_fused_fwd_ws(f, 10, 64, 0, f, 10, 64, 0, sg, 0, f, f, f, 32, GS_ACT_RELU, 0, f, nullptr, nullptr, f, 16, nullptr));
+    REFUSED(GS_EINVAL, gs_sage_fused_fwd_ws(f, 10, 256, 0, f, 10, 256, 0, sg, 2, f, f, f, 256, GS_ACT_RELU, 0, f, nullptr, nullptr, f, 1000, nullptr));
+    REFUSED(GS_EINVAL, gs_sage_fused_fwd_ws(f, 10, 64, 0, f, 10, 64, 0, sg, 9, f, f, f, 32, GS_ACT_RELU, 0, f, nullptr, nullptr, nullptr, 0, nullptr));
 
     // ---- fused layer with draws inside: sampling descriptor and draw table ----
     gs_fused_sampling sp{};

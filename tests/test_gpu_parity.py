@@ -509,7 +509,12 @@ def test_aggregator_layer_call_convention(cuda):
 @pytest.mark.parametrize('fs,fn,h', [(64, 64, 32), (32, 32, 32), (64, 64, 64), (128, 64, 32), (32, 128, 64),
                                      (256, 256, 256), (64, 128, 256), (128, 96, 512)])   # the last three: wide kernel
 @pytest.mark.parametrize('act,normalize', [('relu', False), ('linear', True)])
-def test_fused_layer_matches_oracle(cuda, fs, fn, h, act, normalize):
+@pytest.mark.parametrize('pieces', [True, False])
+def test_fused_layer_matches_oracle(cuda, fs, fn, h, act, normalize, pieces):
+    """``pieces``: wide layers have two forms of the matrix product (bf16 pieces of the fp32 operands on the
+    matrix cores / the fp32 matrix instruction); narrow layers have one and ignore the switch."""
+    if not pieces and h < 256:
+        pytest.skip("one form only")
     rng = np.random.default_rng(fs + fn + h)
     gen = torch.Generator().manual_seed(fs * 7 + h)
     n_self, n_neigh, off_s, off_n = 500, 300, 11, 1000
@@ -548,7 +553,7 @@ def test_fused_layer_matches_oracle(cuda, fs, fn, h, act, normalize):
     save_m = torch.empty((rows, fn), device=cuda)
     assert kernels.fused_supported(fs, fn, h, 25)
     got = kernels.sage_fused(d(t_self), off_s, d(t_neigh), off_n, segs, f32(ws), f32(wn), f32(bias), act,
-                             normalize=normalize, save_self=save_s, save_mean=save_m)
+                             normalize=normalize, save_self=save_s, save_mean=save_m, exact_pieces=pieces)
     close(got, want, scale=float(want.abs().max()))
     np.testing.assert_array_equal(save_s.cpu().numpy(), torch.cat(want_self).float().numpy())
     close(save_m, torch.cat(want_mean), scale=1.0)
@@ -556,7 +561,8 @@ def test_fused_layer_matches_oracle(cuda, fs, fn, h, act, normalize):
     # dense addressing (layer >= 1): heads and children are rows of activation buffers
     n_heads, n_child = 45, 5
     dense = [{'n_heads': n_heads, 'n_child': n_child, 'self_row0': 3, 'child_row0': 10}]
-    got2 = kernels.sage_fused(d(t_self), 0, d(t_neigh), 0, dense, f32(ws), f32(wn), None, act, normalize=normalize)
+    got2 = kernels.sage_fused(d(t_self), 0, d(t_neigh), 0, dense, f32(ws), f32(wn), None, act, normalize=normalize,
+                              exact_pieces=pieces)
     xs = torch.from_numpy(t_self[3:3 + n_heads].astype(np.float64))
     xn = torch.from_numpy(t_neigh[10:10 + n_heads * n_child].astype(np.float64)).reshape(n_heads, 1, n_child, fn)
     o = omodel.aggregator(xs[:, None, :], xn, ws, wn, None, act)[:, 0, :]
@@ -568,8 +574,9 @@ def test_fused_layer_matches_oracle(cuda, fs, fn, h, act, normalize):
     assert not kernels.fused_supported(48, 64, 256, 5) and kernels.fused_supported(256, 256, 256, 5)
 
 
+@pytest.mark.parametrize('pieces', [True, False])
 @pytest.mark.parametrize('fs,fn,h,n_child', [(64, 96, 256, 5), (256, 256, 256, 12), (64, 64, 256, 32)])
-def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_child):
+def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_child, pieces):
     """More 128-head tiles than blocks: every block walks several tiles (ids staged one
     tile ahead, operand stages alternating across tile borders).  Checked against gather +
     gather-mean + projection, and a sample of rows against the float64 oracle."""
@@ -598,7 +605,7 @@ def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_
     rows = want.shape[0]
     save_s, save_m = torch.empty((rows, fs), device=cuda), torch.empty((rows, fn), device=cuda)
     got = kernels.sage_fused(t_self, off_s, t_neigh, off_n, segs, f32(ws), f32(wn), f32(bias), 'relu',
-                             save_self=save_s, save_mean=save_m)
+                             save_self=save_s, save_mean=save_m, exact_pieces=pieces)
     close(got, want, scale=float(want.abs().max()))
     # rows of the first tiles, a tile border in the middle, and the tail against the float64 restatement
     pick = torch.cat([torch.arange(0, 200), torch.arange(128 * 257 - 20, 128 * 257 + 20), torch.arange(rows - 400, rows)])

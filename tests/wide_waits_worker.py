@@ -44,11 +44,12 @@ def main():
             sv = {}
             if case % 2 == 0:
                 sv = {'save_self': torch.zeros((rows, fs), device=dev), 'save_mean': torch.zeros((rows, fn), device=dev)}
-            got = kernels.sage_fused(t_self, off_s, t_neigh, off_n, segs, ws, wn, bias, 'relu', **sv)
-            torch.cuda.synchronize()
-            outs['out%d' % case] = got.cpu()
-            for k, v in sv.items():
-                outs['%s%d' % (k, case)] = v.cpu()
+            for pieces in (True, False):                # both forms of the product share the producers
+                got = kernels.sage_fused(t_self, off_s, t_neigh, off_n, segs, ws, wn, bias, 'relu', exact_pieces=pieces, **sv)
+                torch.cuda.synchronize()
+                outs['out%d_%d' % (case, pieces)] = got.cpu()
+                for k, v in sv.items():
+                    outs['%s%d_%d' % (k, case, pieces)] = v.cpu()
             case += 1
     torch.save(outs, args.out)
     print("wide_waits_worker: %d cases on %s" % (case, kernels._lib.LIB_PATH))
