@@ -101,7 +101,7 @@ class SageWeights(_c.Structure):
 class Sage2Saved(_c.Structure):
     """gs_sage2_saved of include/gsage.h."""
     _fields_ = [('x_self', _vp * 2), ('x_mean', _vp * 2), ('h1', _vp * 2), ('x_mean1', _vp * 2), ('z', _vp * 2),
-                ('self_ids', _vp * 2), ('h1_mask', _vp * 2)]
+                ('self_ids', _vp * 2), ('h1_mask', _vp * 2), ('dropout_rate', _c.c_float), ('dropout_seed', _u64)]
 
 
 class Sage2Subtrees(_c.Structure):
@@ -112,7 +112,7 @@ class Sage2Subtrees(_c.Structure):
 
 class Sage2L0Mask(_c.Structure):
     """gs_sage2_l0_mask of include/gsage.h."""
-    _fields_ = [('h1', _vp * 2), ('h1_mask', _vp * 2)]
+    _fields_ = [('h1', _vp * 2), ('h1_mask', _vp * 2), ('input_scale', _c.c_float)]
 
 
 SIGNATURES['gs_sage2_supported'] = (_i32, [_i32] * 6)

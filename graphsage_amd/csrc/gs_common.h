@@ -83,4 +83,40 @@ __device__ __forceinline__ uint32_t philox4x32_10_x(uint32_t c0, uint32_t c1, ui
     return c0;
 }
 
+// Philox4x32-10, all four output words.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += W0;
+        k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Dropout of the aggregator inputs (models.py:152,165), addressed like the sampling draws: the four columns
+// 4*c4 .. 4*c4+3 of row `row` of input `site` of walk `walk` are kept where the four words of
+// Philox(counter = (walk lo, walk hi, kDropSite | site, row * 64 + c4), key = dropout seed) are >= threshold
+// (= rate * 2^32, rounded down); kept values are scaled by 1 / (1 - rate).  Sites of a two-hop walk: 0 the
+// hop-2 rows (neighbors of the hop-1 heads, row = j * n1 + k), 1 the hop-1 rows as heads, 2 the hop-1 rows as the
+// root's neighbors, 3 the root's row, 4 the layer-1 inputs (row 0 the root's activation, row 1 + j hop-1 head j's).
+constexpr uint32_t kDropSite = 0x40000000u;
+struct DropKey {
+    uint32_t wlo, whi, k0, k1, thr;
+    __device__ __forceinline__ float4 apply(float4 v, uint32_t site, uint32_t row, uint32_t c4, float scale) const {
+        uint32_t w[4];
+        philox4x32_10(wlo, whi, kDropSite | site, row * 64u + c4, k0, k1, w);
+        return make_float4(w[0] >= thr ? v.x * scale : 0.f, w[1] >= thr ? v.y * scale : 0.f,
+                           w[2] >= thr ? v.z * scale : 0.f, w[3] >= thr ? v.w * scale : 0.f);
+    }
+};
+
 }  // namespace gs

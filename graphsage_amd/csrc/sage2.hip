@@ -71,6 +71,9 @@ struct Sage2Args {
     float *sv_x_mean1[2], *sv_z[2];                   // n_pairs rows: layer-1 neighbor mean, pre-norm output
     int32_t *sv_self_ids[2];                          // same rows as sv_x_self: the node id instead of its feature row
     uint32_t *sv_h1_mask[2];                          // n_pairs * n0 * H1/32 words: [h1 > 0] of the hop-1 heads, instead of their rows
+    // training with dropout (DROP instantiations): threshold rate * 2^32, 1 / (1 - rate), key
+    uint32_t drop_thr, drop_k0, drop_k1;
+    float drop_scale;
     // Subtree mode (sub_n > 0): root i is hop-1 node i % sub_n of seed walk i / sub_n of a deeper model, whose
     // hops 1 and 2 this kernel draws (sampler hop = local hop + 1, slots shifted by the subtree's position);
     // the item-typed roots come first (they hang below the user-rooted seed walks).
@@ -104,7 +107,7 @@ struct Sage2Shape {
 };
 
 // One walk.  FT / FO: feature widths of the root's type and of the other type.
-template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, bool SAVE>
+template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, bool SAVE, bool DROP>
 __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int side, int lane,
                                           int32_t root, int64_t ra, int64_t rb,
                                           int32_t next_root, int64_t &next_ra, int64_t &next_rb,
@@ -129,6 +132,8 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     if (root < 0 && lane == 0) atomicMax(&a.err[1], 1);
     const unsigned long long walk = a.walk_ids ? (unsigned long long)a.walk_ids[w] : a.walk_base + (unsigned long long)w;
     const unsigned wlo = (unsigned)walk, whi = (unsigned)(walk >> 32);
+    const gs::DropKey dk{wlo, whi, a.drop_k0, a.drop_k1, a.drop_thr};       // (DROP only)
+    const float dscale = a.drop_scale;
     const uint32_t *tape = a.replay ? a.replay + (size_t)w * (n0 + n0 * n1) : nullptr;
     const uint32_t *tape0 = tape;
     const uint32_t *tape1 = tape ? tape + n0 : nullptr;
@@ -238,6 +243,11 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
                     for (int hd = 0; hd < kHeads; ++hd)
 #pragma unroll
                         for (int u = 0; u < kUnroll; ++u) {
+                            if (DROP) {
+                                const int pp = pp0 + hd * GN_T;
+                                if (pp < np && u < per && c0 + u < n1)
+                                    v[hd][u] = dk.apply(v[hd][u], 0u, (uint32_t)((j0 + pp) * n1 + c0 + u), (uint32_t)c, dscale);
+                            }
                             acc[hd].x += v[hd][u].x; acc[hd].y += v[hd][u].y;
                             acc[hd].z += v[hd][u].z; acc[hd].w += v[hd][u].w;
                         }
@@ -266,10 +276,15 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
 #pragma unroll
         for (int pass = 0; pass < NPASS_O; ++pass) {
             const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
-            *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = own[pass];
+            float4 as_head = own[pass], as_neigh = own[pass];
+            if (DROP) {                      // the same rows enter twice, each time behind its own Dropout (models.py:152,165)
+                as_head = dk.apply(own[pass], 1u, (uint32_t)(j0 + rr), (uint32_t)c, dscale);
+                as_neigh = dk.apply(own[pass], 2u, (uint32_t)(j0 + rr), (uint32_t)c, dscale);
+            }
+            *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = as_head;
             if (SAVE && a.sv_x_self[1 - side] && rr < np)
-                stream_store(a.sv_x_self[1 - side] + (size_t)(sv_h1row + j0 + rr) * FO + 4 * c, own[pass]);
-            rootsum.x += own[pass].x; rootsum.y += own[pass].y; rootsum.z += own[pass].z; rootsum.w += own[pass].w;
+                stream_store(a.sv_x_self[1 - side] + (size_t)(sv_h1row + j0 + rr) * FO + 4 * c, as_head);
+            rootsum.x += as_neigh.x; rootsum.y += as_neigh.y; rootsum.z += as_neigh.z; rootsum.w += as_neigh.w;
         }
         wave_lds_fence();
         mma_tile<FO, NT1>(A, LDA, W0s_O, wl, r, q, acc_s);
@@ -300,6 +315,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         float4 own_root = make_float4(0.f, 0.f, 0.f, 0.f);
         {
             own_root = tabT.load(root >= 0 && lane < FTV, (unsigned)(root - offT), (unsigned)(lane % FTV) * 16u, FT * 4);
+            if (DROP && lane < FTV) own_root = dk.apply(own_root, 3u, 0u, (uint32_t)lane, dscale);
         }
         if (lane < FOV) {
             const float4 mean = make_float4(rootsum.x / d0, rootsum.y / d0, rootsum.z / d0, rootsum.w / d0);
@@ -328,6 +344,16 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     }
 
     // ---- layer 1 on the LDS-resident activations (root only, type T) ---------------------
+    if (DROP) {
+        // Dropout of the layer-1 inputs, in place: row 0 (the root's activation, its own input) and rows 1 .. n0
+        // (the hop-1 heads', its neighbors).  What is saved below are these values: relu keeps them >= 0, so
+        // "> 0" afterwards says "active and kept", which is all the backward pass asks of them.
+        for (int i = lane; i < (1 + n0) * H1V; i += 64) {
+            float4 *pv = reinterpret_cast<float4 *>(H1t + (i / H1V) * LDH + 4 * (i % H1V));
+            *pv = dk.apply(*pv, 4u, (uint32_t)(i / H1V), (uint32_t)(i % H1V), dscale);
+        }
+        wave_lds_fence();
+    }
     {
         constexpr int G1 = 64 / H1V;
         const int g = lane / H1V, c = lane % H1V;
@@ -740,7 +766,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
     }
 }
 
-template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB>
+template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB, bool DROP = false>
 __global__ __launch_bounds__(block_waves(HH1, SAVE, SUB) * 64)
 void sage2_kernel(const Sage2Args a) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
@@ -856,16 +882,16 @@ void sage2_kernel(const Sage2Args a) {
         const int32_t next_root = pn < a.n_pairs ? load_root(pn) : -1;
         int64_t nra = 0, nrb = 0;
         if (side == 0)
-            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF, SAVE>(a, base + p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FU, FI, HH1, HH2, LDA, LDH, BUF, SAVE, DROP>(a, base + p, 0, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_u, w0n_u, w0s_i, w0n_i, w1s, w1n, bias, bias + H1, bias + 2 * H1);
         else
-            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF, SAVE>(a, base + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
+            walk_body<FI, FU, HH1, HH2, LDA, LDH, BUF, SAVE, DROP>(a, base + p, 1, lane, root, ra, rb, next_root, nra, nrb, A, H1t, s_ids,
                                                   w0s_i, w0n_i, w0s_u, w0n_u, w1s, w1n, bias + H1, bias, bias + 2 * H1);
         root = next_root; ra = nra; rb = nrb;
     }
 }
 
-template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB = false>
+template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB = false, bool DROP = false>
 int launch_one(const Sage2Args &a, hipStream_t stream) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     constexpr int roots = SUB ? kGroup : 0;
@@ -873,7 +899,7 @@ int launch_one(const Sage2Args &a, hipStream_t stream) {
     while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves, roots) > kLdsMax) waves -= 2;
     const size_t lds = S::lds_bytes(a.n0, a.n1, waves, roots);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
-    auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF, SAVE, SUB>;
+    auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF, SAVE, SUB, DROP>;
     if (lds > 64 * 1024) {
         hipError_t e = gs::raise_lds_limit((const void *)kern, (int)kLdsMax);
         if (e != hipSuccess) return gs::fail(GS_ELAUNCH, "gs_sage2_forward: cannot raise the LDS limit: %s", hipGetErrorString(e));
@@ -890,6 +916,8 @@ int launch(const Sage2Args &a, hipStream_t stream) {
     const long long lim = 0xFFFFF000LL;                  // RowTable::kNoRow must lie past the end of both tables
     const bool buf = a.n_rows[0] * FU * 4 < lim && a.n_rows[1] * FI * 4 < lim;
     if (a.sub_n) return buf ? launch_one<FU, FI, HH1, HH2, true, false, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, false, true>(a, stream);
+    if (a.sv_z[0] && a.drop_thr)
+        return buf ? launch_one<FU, FI, HH1, HH2, true, true, false, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, true, false, true>(a, stream);
     if (a.sv_z[0]) return buf ? launch_one<FU, FI, HH1, HH2, true, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, true>(a, stream);
     return buf ? launch_one<FU, FI, HH1, HH2, true, false>(a, stream) : launch_one<FU, FI, HH1, HH2, false, false>(a, stream);
 }
@@ -997,6 +1025,19 @@ int sage2_forward_impl(const int64_t *indptr, const int32_t *indices, int64_t n_
         }
         if (!saved->h1_mask[0] != !saved->h1_mask[1])
             return gs::fail(GS_EINVAL, "gs_sage2_forward: h1_mask must be given for both node types or for none");
+        if (!(saved->dropout_rate >= 0.f) || saved->dropout_rate >= 1.f)
+            return gs::fail(GS_EINVAL, "gs_sage2_forward: dropout_rate=%g outside [0, 1)", (double)saved->dropout_rate);
+        if (saved->dropout_rate > 0.f) {
+            // the backward pass reads "active and kept" from what is saved: mask words for the hop-1 heads, and
+            // the own rows as they entered the layer (not their ids)
+            if (!saved->h1_mask[0] || !saved->x_self[0] || !saved->x_self[1])
+                return gs::fail(GS_EINVAL, "gs_sage2_forward: dropout needs saved->h1_mask and saved->x_self");
+            const double thr = (double)saved->dropout_rate * 4294967296.0;
+            a.drop_thr = (uint32_t)(thr < 1.0 ? 1.0 : thr);
+            a.drop_scale = 1.0f / (1.0f - saved->dropout_rate);
+            a.drop_k0 = (uint32_t)saved->dropout_seed; a.drop_k1 = (uint32_t)(saved->dropout_seed >> 32);
+            for (int t = 0; t < 2; ++t) a.sv_self_ids[t] = nullptr;
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     const int hh1 = H1 / 2, hh2 = H2 / 2;

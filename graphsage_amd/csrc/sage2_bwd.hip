@@ -37,6 +37,7 @@ struct TailArgs {
     // layer-0 relu masks (or NULL): the roots' saved layer-0 outputs, the hop-1 heads' mask words
     const float *h1[2];
     const uint32_t *h1_mask[2];
+    float in_scale;                          // factor on the layer-1 input gradients (dropout's 1 / (1 - rate); 1 otherwise)
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -138,8 +139,10 @@ void sage2_tail_bwd_kernel(const TailArgs a) {
             ds = fmaf(gz_s[n], ws[n * H1 + k], ds);
             dn = fmaf(gz_s[HH2 + n], wn[n * H1 + k], dn);
         }
+        ds *= a.in_scale;
+        dn *= a.in_scale;
         if (lane < H1) {
-            if (a.h1[t] && !(a.h1[t][p * H1 + lane] > 0.f)) ds = 0.f;     // through layer 0's activation
+            if (a.h1[t] && !(a.h1[t][p * H1 + lane] > 0.f)) ds = 0.f;     // through layer 0's activation (and its dropout)
             a.g_h1[t][p * H1 + lane] = ds;
         }
         // the n0 hop-1 heads of this walk: n0 * H1 consecutive floats repeating the H1 values dn / n0.  Stored
@@ -205,7 +208,9 @@ int launch_tail(const TailArgs &a, bool head, hipStream_t s) {
 }
 
 int set_l0_mask(TailArgs &a, const gs_sage2_l0_mask *m, const char *who) {
+    a.in_scale = 1.f;
     if (!m) return GS_OK;
+    if (m->input_scale != 0.f) a.in_scale = m->input_scale;
     for (int t = 0; t < 2; ++t) {
         if (!m->h1[t] || !m->h1_mask[t]) return gs::fail(GS_EINVAL, "%s: l0_mask has a null pointer", who);
         a.h1[t] = m->h1[t];

@@ -468,6 +468,7 @@ def _l0_mask_struct(l0_mask, b, n0, h1):
     if l0_mask is None:
         return None, None
     st = _lib.Sage2L0Mask()
+    st.input_scale = float(l0_mask.get('input_scale', 0.0))
     for i, t in enumerate(('user', 'item')):
         rows, words = l0_mask['h1'][t], l0_mask['h1_mask'][t]
         _dev(rows, torch.float32, 'l0_mask[h1][%s]' % t, 2)
@@ -716,6 +717,11 @@ def sage_fused(feat_self, off_self, feat_neigh, off_neigh, segments, w_self, w_n
                           normalize, out, save_self, save_mean, exact_pieces=exact_pieces).run()
 
 
+def dropout_seed_of(rng_seed):
+    """Key of a step's dropout masks, from the key of its sampling draws (another stream of the same generator)."""
+    return (int(rng_seed) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
 def sage2_supported(fu, fi, h1, h2, n0, n1):
     return bool(load().gs_sage2_supported(int(fu), int(fi), int(h1), int(h2), int(n0), int(n1)))
 
@@ -839,6 +845,13 @@ class Sage2Call:
                     if buf.numel() != self.n_pairs * n0 * (h1 // 32):
                         raise ValueError("saved[h1_mask][%s] must have %d words" % (t, self.n_pairs * n0 * (h1 // 32)))
                     st.h1_mask[i] = buf.data_ptr()
+            rate = float(saved.get('dropout', 0.0) or 0.0)
+            if rate:
+                if not 0.0 < rate < 1.0:
+                    raise ValueError("dropout rate must lie in [0, 1)")
+                if saved.get('self_ids') is not None or saved.get('h1_mask') is None:
+                    raise ValueError("dropout needs saved['x_self'] (not self_ids) and saved['h1_mask']")
+                st.dropout_rate = rate
             self._saved = st
         self._lib = lib
         self._keep = [indptr, indices, feat_user, feat_item, weights, saved]
@@ -861,6 +874,8 @@ class Sage2Call:
     def run(self, seeds, err_flag, rng_seed=0, walk_id_base=0, walk_ids=None, replay=None):
         if self._epoch != _storage_epoch:
             self._read_weight_addresses()
+        if self._saved is not None and self._saved.dropout_rate:
+            self._saved.dropout_seed = dropout_seed_of(rng_seed)
         _dev(seeds, torch.int32, 'seeds', 1)
         _dev(err_flag, torch.int32, 'err_flag', 1)
         draw_hop1 = self._sub is not None and self._draw_hop1

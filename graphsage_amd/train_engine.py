@@ -23,9 +23,9 @@ class SageTrainEngine(SageForwardEngine):
         # Feature widths that are not multiples of 32 (MovieLens: 28 / 18 columns) run through zero-padded
         # copies of the tables and of the layer-0 weights; the real weights and their gradients are copied
         # in and out around every pass (padding.py).
-        if getattr(model, 'dropout', 0.0):
-            raise kernels._lib.GsageError("the training plan has no dropout; a model with dropout > 0 trains through "
-                                          "graphsage_amd.train.Trainer(engine='autograd')")
+        self.dropout = float(getattr(model, 'dropout', 0.0) or 0.0)
+        if not 0.0 <= self.dropout < 1.0:
+            raise ValueError("dropout rate must lie in [0, 1)")
         self._padded_model = None
         f = graph.node_feature_sizes
         if any(f[t] % 32 for t in _TYPES):
@@ -84,6 +84,15 @@ class SageTrainEngine(SageForwardEngine):
             words = self.batch * self.fanouts[0] * (m.dims[1]['user'] // 32)
             self.h1_mask = {t: torch.zeros(words, dtype=torch.int32, device=dev) for t in _TYPES}
         self._head_slab = None
+        # Dropout of the aggregator inputs (models.py:152,165) is drawn inside the one-kernel forward; what that
+        # kernel saves are the inputs as they entered the layers, so the own rows are saved as rows (not ids) and
+        # the masks carry "active and kept".
+        if self.dropout:
+            if not (self.walk_train and self._tail_kernel and self.h1_mask is not None):
+                raise kernels._lib.GsageError(
+                    "the training plan draws dropout in its two-hop one-kernel route only; this model trains through "
+                    "graphsage_amd.train.Trainer(engine='autograd')")
+            self.self_ids = None
 
     @property
     def tail_kernel(self):
@@ -93,6 +102,8 @@ class SageTrainEngine(SageForwardEngine):
     def tail_kernel(self, on):
         """Switching the one-launch top of the backward pass off (comparisons, tests) also brings back
         the gathered copy of the own rows, which the layer-by-layer backward kernels read."""
+        if self.dropout and not on:
+            raise kernels._lib.GsageError("dropout is drawn by the one-kernel route only")
         self._tail_kernel = bool(on) and self.walk_train
         if not self._tail_kernel and (self.self_ids is not None or self.h1_mask is not None):
             self.self_ids = None
@@ -113,6 +124,8 @@ class SageTrainEngine(SageForwardEngine):
                 del saved['x_self']
             if self.h1_mask is not None:
                 saved['h1_mask'] = self.h1_mask
+            if self.dropout:
+                saved['dropout'] = self.dropout
             self._walk_train_call = kernels.Sage2Call(
                 self.indptr, self.indices, self.tables['user'][0], self.tables['item'][0], self.fanouts, weights,
                 m.normalize == "l2", self.batch, emb=self.emb_all, saved=saved)
@@ -227,6 +240,8 @@ class SageTrainEngine(SageForwardEngine):
             self._side2 = torch.cuda.Stream()
         top = m._aggs[1]
         l0_mask = None if self.h1_mask is None else {'h1': self.h[0], 'h1_mask': self.h1_mask}
+        if self.dropout:
+            l0_mask['input_scale'] = 1.0 / (1.0 - self.dropout)
         if head is None:
             kernels.sage2_backward_tail(self.z, {'user': g_user.contiguous(), 'item': g_item.contiguous()},
                                         {t: top[t].w_self for t in _TYPES}, {t: top[t].w_neigh for t in _TYPES},

@@ -447,6 +447,16 @@ typedef struct gs_sage2_saved {
                                x_mean1), so with h1_mask they are NOT written; bit c % 32 of word
                                (row - n_pairs) * H1/32 + c / 32 says whether h1[row, c] > 0.  gs_sage2_backward_tail
                                applies these masks (its l0_mask argument) */
+    float dropout_rate;     /* 0: none.  In (0, 1): Dropout of every aggregator input (models.py:152,165), addressed
+                               like the draws so that it can be restated: the four columns 4*c4 .. 4*c4+3 of row
+                               `row` of input `site` of walk w are kept where the four words of Philox4x32-10(counter
+                               = (walk id lo, hi, 0x40000000 | site, row * 64 + c4), key = dropout_seed) are >=
+                               floor(rate * 2^32), and scaled by 1 / (1 - rate).  Sites: 0 hop-2 rows (row = j * n1 +
+                               k), 1 hop-1 rows as heads, 2 hop-1 rows as the root's neighbors, 3 the root's row, 4 the
+                               layer-1 inputs (row 0 the root's layer-0 output, row 1 + j hop-1 head j's).  Needs
+                               x_self and h1_mask (self_ids is ignored): what is saved are the inputs as they entered
+                               the layers, and h1 / h1_mask then say "active and kept" */
+    uint64_t dropout_seed;
 } gs_sage2_saved;
 
 int gs_sage2_supported(int Fu, int Fi, int H1, int H2, int n0, int n1);
@@ -547,6 +557,9 @@ int gs_sage3_seeds_forward(const float *feat_user, int64_t n_users, int Fu,
 typedef struct gs_sage2_l0_mask {
     const float *h1[2];
     const uint32_t *h1_mask[2];
+    float input_scale;      /* 0 or 1: none.  Otherwise the factor the forward pass applied to the layer-1 inputs it kept
+                               (dropout: 1 / (1 - rate), gs_sage2_saved.dropout_rate); the gradients that pass the
+                               masks are multiplied by it */
 } gs_sage2_l0_mask;
 
 /*

@@ -103,7 +103,10 @@ def init_weights(plan, gen, bias=True, dtype=torch.float32):
     return weights
 
 
-def forward(plan, weights, xin, normalize='l2', keep_layers=None, agg='mean'):
+def forward(plan, weights, xin, normalize='l2', keep_layers=None, agg='mean', dropout=None):
+    """``dropout``: None, or ``hook(layer, slot, role, x)`` returning x behind the Dropout layer
+    ``models.py:152`` (role 'neigh') / ``models.py:165`` (role 'head') puts in front of aggregator call ``slot``
+    of ``layer`` (see ``oracle.dropout``)."""
     h = list(xin)
     for layer in range(plan.n_layers):
         out = []
@@ -113,7 +116,11 @@ def forward(plan, weights, xin, normalize='l2', keep_layers=None, agg='mean'):
             n_dim = plan.dims[layer][plan.schema[j][0]]
             x_neigh = h[j].reshape(h[j].shape[0], heads, plan.n_samples[plan.depths[i]], n_dim)
             w = weights[(layer, node_type)]
-            out.append(aggregator(h[i], x_neigh, w['w_self'], w['w_neigh'], w['bias'],
+            x_head = h[i]
+            if dropout is not None:
+                x_neigh = dropout(layer, i, 'neigh', x_neigh)
+                x_head = dropout(layer, i, 'head', x_head)
+            out.append(aggregator(x_head, x_neigh, w['w_self'], w['w_neigh'], w['bias'],
                                   plan.activations[layer], agg))
         h = out
         if keep_layers is not None:

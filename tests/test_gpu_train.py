@@ -73,14 +73,20 @@ def test_one_step_matches_oracle(cuda):
         assert float((got - want)[big].abs().max()) < 1e-4 if big.any() else True
 
 
-def test_short_run_learns(cuda):
+@pytest.mark.parametrize('rate', [0.0, 0.2])
+def test_short_run_learns(cuda, rate):
+    """(rate > 0: the plan's own dropout, through fit-style steps on padded 24/19-wide tables)"""
     g, links, targets = _toy(1)
     gen = ga.GraphSAGEGenerator(g, 100, [8, 4], head_node_types=['user', 'item'], seed=5)
-    model = ga.GraphSAGE([32, 32], gen, seed=2)
-    tr = Trainer(model, lr=1e-2)
+    model = ga.GraphSAGE([32, 32], gen, dropout=rate, seed=2)
+    tr = Trainer(model, lr=1e-2) if not rate else Trainer(model, lr=1e-2, graph=g, batch_size=100)
+    assert (tr.engine is not None) == bool(rate)
     seq = gen.flow(links, targets=targets, shuffle=True, seed=1)
     losses = []
-    for epoch in range(15):
+    if rate:
+        losses = tr.fit(seq, epochs=15, verbose=0)['loss']       # full batches: replayed plan steps with dropout
+        assert tr._n_graph_steps > 0
+    for epoch in range(0 if rate else 15):
         tot = 0.0
         for batch, t in seq:
             loss, _ = tr.step(batch, t)
@@ -191,14 +197,17 @@ def test_link_head_kernel_and_adam_kernel(cuda):
         np.testing.assert_allclose(pf.cpu().numpy(), x, rtol=2e-5, atol=1e-6)
 
 
-def test_graph_replayed_steps_equal_eager_steps(cuda):
+@pytest.mark.parametrize('rate', [0.0, 0.2])
+def test_graph_replayed_steps_equal_eager_steps(cuda, rate):
+    """(with dropout as well: the masks are a function of key, walk and position, so a replayed step draws what
+    the eager step draws)"""
     g, links, targets = _toy(4, fu=64, fi=64)
     b, ns, sizes = 32, [6, 3], [32, 32]
     lk = np.asarray(links)
     outs = []
     for mode in ('eager', 'graph'):
         gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
-        model = ga.GraphSAGE(sizes, gen, seed=11).build()
+        model = ga.GraphSAGE(sizes, gen, dropout=rate, seed=11).build()
         from graphsage_amd.train import LinkHead
         tr = Trainer(model, head=LinkHead(32, cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
         losses = []
@@ -328,16 +337,100 @@ def test_staged_epoch_rows_equal_the_per_batch_roots(cuda):
         bad.epoch_on_device()
 
 
-def test_dropout_models_train_through_autograd(cuda):
-    """The static plan implements no dropout (models.py:113-115 applies it to every layer input while
-    training): 'auto' must not pick it, 'plan' must refuse."""
+def test_dropout_models_and_the_training_plan(cuda):
+    """Dropout on every aggregator input (models.py:152,165) is drawn inside the two-hop one-kernel route of the
+    static plan; other depths have no such kernel: 'auto' takes autograd for them, 'plan' refuses."""
     g, links, targets = _toy(1, fu=32, fi=32)
-    gen = ga.GraphSAGEGenerator(g, 16, [3, 2], head_node_types=['user', 'item'], seed=1)
-    model = ga.GraphSAGE([32, 32], gen, dropout=0.5, seed=2)
-    assert Trainer(model, lr=1e-2, graph=g, batch_size=16).engine is None
+    gen2 = ga.GraphSAGEGenerator(g, 16, [3, 2], head_node_types=['user', 'item'], seed=1)
+    gen3 = ga.GraphSAGEGenerator(g, 16, [3, 2, 2], head_node_types=['user', 'item'], seed=1)
+    tr = Trainer(ga.GraphSAGE([32, 32], gen2, dropout=0.5, seed=2), lr=1e-2, graph=g, batch_size=16)
+    assert tr.engine is not None and tr.engine.dropout == 0.5 and tr.engine.self_ids is None
+    deep = ga.GraphSAGE([32, 32, 32], gen3, dropout=0.5, seed=2)
+    assert Trainer(deep, lr=1e-2, graph=g, batch_size=16).engine is None
     with pytest.raises(Exception):
-        Trainer(model, lr=1e-2, engine='plan', graph=g, batch_size=16)
-    assert Trainer(ga.GraphSAGE([32, 32], gen, seed=2), lr=1e-2, graph=g, batch_size=16).engine is not None
+        Trainer(deep, lr=1e-2, engine='plan', graph=g, batch_size=16)
+    with pytest.raises(Exception):
+        Trainer(ga.GraphSAGE([32, 32], gen2, dropout=1.0, seed=2), lr=1e-2, engine='plan', graph=g, batch_size=16)
+    assert Trainer(ga.GraphSAGE([32, 32, 32], gen3, seed=2), lr=1e-2, graph=g, batch_size=16).engine is not None
+
+
+@pytest.mark.parametrize('ns,sizes,f,rate', [([6, 3], [32, 32], 64, 0.3), ([25, 10], [32, 32], 64, 0.1), ([5, 4], [64, 64], 32, 0.5),
+                                             ([3, 2], [32, 32], 128, 0.25)])
+def test_plan_step_with_dropout_equals_the_oracle_fed_the_same_masks(cuda, ns, sizes, f, rate):
+    """One optimisation step of the static plan with dropout > 0 against the float64 restatement given the masks
+    the device's rule defines (oracle/dropout.py): loss, predictions, every gradient.  A second step on the same
+    inputs repeats the first bit for bit (the masks are a function of seed, walk and position), another seed
+    does not, and rate 0 leaves the step what it was."""
+    from graphsage_amd.train import LinkHead
+    from graphsage_amd import kernels
+    from oracle import dropout as odrop
+    g, links, targets = _toy(3, fu=f, fi=f)
+    b = 40
+    lk = np.asarray(links[:b])
+    seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+    walk_ids = torch.arange(2 * b, dtype=torch.int64, device=cuda) * 3 + (1 << 34)
+    t = torch.from_numpy(targets[:b]).to(cuda)
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+
+    def step(drop, rng_seed, lr=0.0):
+        model = ga.GraphSAGE(sizes, gen, dropout=drop, seed=11).build()
+        bias_gen = torch.Generator().manual_seed(1)
+        for p in model.parameters():
+            if p.dim() == 1:                                 # a zero bias would hide a misplaced one
+                p.data.copy_(torch.rand(p.shape, generator=bias_gen) * 0.2 - 0.1)
+        tr = Trainer(model, head=LinkHead(sizes[-1], cuda, seed=5), lr=lr, engine='plan', graph=g, batch_size=b)
+        loss, pred = tr.step_device(seeds, t, walk_ids, rng_seed=rng_seed)
+        assert tr.engine.err_flag.tolist() == [0, 0]
+        return tr, model, float(loss), pred.detach().reshape(-1).cpu().clone(), tr.bucket.flat.detach().cpu().clone()
+
+    tr, model, loss, pred, grads = step(rate, 77)
+    # the oracle: the same draws (gs_sample), rows by torch indexing, float64, masks by the stated rule
+    dev = g.device_tensors()
+    hops, _ = kernels.sample(dev['indptr'], dev['indices'], seeds, ns, rng_seed=77, walk_ids=walk_ids)
+    slot_ids = [seeds[:b].reshape(b, 1), seeds[b:].reshape(b, 1)]
+    for hop in hops:
+        slot_ids += [hop[:b], hop[b:]]
+    nu = g.num_users
+    xin = []
+    for s_, ids in enumerate(slot_ids):
+        ty = ('user', 'item')[(s_ % 2 + s_ // 2) % 2]
+        x = dev[ty][ids.reshape(-1).long() - (nu if ty == 'item' else 0)].cpu().double()
+        xin.append(x.reshape(b, -1, x.shape[1]))
+    plan = omodel.LayerPlan(sizes, ns, g.node_feature_sizes)
+    weights = {(l, ty): {'w_self': a.w_self.detach().cpu().double().requires_grad_(True),
+                         'w_neigh': a.w_neigh.detach().cpu().double().requires_grad_(True),
+                         'bias': a.bias.detach().cpu().double().requires_grad_(True)}
+               for l, aggs in enumerate(model._aggs) for ty, a in aggs.items()}
+    kernel = tr.head.kernel.detach().cpu().double().requires_grad_(True)
+    hbias = tr.head.bias.detach().cpu().double().requires_grad_(True)
+    hook = odrop.two_hop(walk_ids.cpu().numpy(), b, ns[0], ns[1], rate, kernels.dropout_seed_of(77))
+    emb = omodel.forward(plan, weights, xin, dropout=hook)
+    want_pred = omodel.link_head(emb[0], emb[1], kernel, hbias)
+    want_loss = omodel.mse_loss(want_pred, t.cpu().double())
+    want_loss.backward()
+    assert abs(loss - float(want_loss)) < 1e-5 * max(1.0, float(want_loss))
+    assert float((pred.double() - want_pred.detach().reshape(-1)).abs().max()) < 2e-6
+    ref = [weights[(l, ty)][n] for l, aggs in enumerate(model._aggs) for ty, a in aggs.items()
+           for n in ('w_self', 'w_neigh', 'bias')] + [kernel, hbias]
+    want_grads = torch.cat([r.grad.reshape(-1) for r in ref])
+    assert want_grads.numel() == grads.numel()
+    off = 0
+    for r in ref:                                        # per parameter: its own scale
+        gr, wg = grads[off:off + r.numel()].double(), r.grad.reshape(-1)
+        off += r.numel()
+        assert float((gr - wg).abs().max()) <= 2e-5 * (float(wg.abs().max()) + 1e-12)
+    # the masks really drop: without them the prediction differs
+    emb0 = omodel.forward(plan, weights, xin)
+    assert float((omodel.link_head(emb0[0], emb0[1], kernel, hbias).detach().reshape(-1) - pred.double()).abs().max()) > 1e-3
+    # deterministic in (seed, walk, position); another seed draws other masks
+    _, _, loss2, pred2, grads2 = step(rate, 77)
+    assert loss2 == loss and torch.equal(pred2, pred) and torch.equal(grads2, grads)
+    _, _, _, pred3, _ = step(rate, 78)
+    assert not torch.equal(pred3, pred)
+    # rate 0 is the plan without dropout (ids instead of rows for the own rows, same numbers as before)
+    tr0, _, loss0, pred0, grads0 = step(0.0, 77)
+    assert tr0.engine.self_ids is not None or f != 64 or sizes[0] != 32
+    assert float((pred0.double() - omodel.link_head(emb0[0], emb0[1], kernel, hbias).detach().reshape(-1)).abs().max()) < 2e-6
 
 
 def test_plan_step_without_bias_and_normalisation_equals_autograd(cuda):
