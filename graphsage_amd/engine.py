@@ -562,8 +562,8 @@ class SageForwardEngine:
             hits = [v for k, v in rec.items() if k.endswith(tail) and any(
                 k.startswith("%s/sage_fused_kernel<%d, %d, %d, false" % (workload, f[t], f[self.other[t]], self.model.dims[1][t] // 2))
                 for t in _TYPES)]
-        elif name == "sage2_kernel":             # <Fu, Fi, H1/2, H2/2, buffer loads, SAVING, SUBTREES>: the forward saves nothing
-            flags = "false, true>" if self.subtree_kernel else "false, false>"
+        elif name == "sage2_kernel":             # <Fu, Fi, H1/2, H2/2, buffer loads, SAVING, SUBTREES, DROPOUT>: the forward saves nothing
+            flags = "false, true, false>" if self.subtree_kernel else "false, false, false>"
             hits = [v for k, v in rec.items() if k.startswith("%s/sage2_kernel<" % workload) and k.endswith(flags + tail)]
         else:
             hits = [v for k, v in rec.items() if k.startswith("%s/%s<" % (workload, name)) and k.endswith(tail)]
