@@ -36,10 +36,14 @@ using namespace gs::tile;
 
 // Waves per block (one block per CU).  With 32-wide activations everything a wave keeps in LDS lets
 // sixteen waves fit: four per SIMD, 128 registers each, one head's children in flight per lane
-// group.  64-wide activations double the weights and the activation rows, at most eight waves
-// fit, so those instantiations are built for eight waves (two per SIMD, 256 registers each) and
-// keep two heads' children in flight per lane group instead: the same bytes in flight per CU.
-constexpr int max_waves(int hh1) { return hh1 >= 32 ? 8 : 16; }
+// group.  64-wide activations double the weights and the activation rows: the forms that keep the rows
+// (saving, subtrees) fit eight waves (two per SIMD, 256 registers each) and keep two heads' children in flight
+// per lane group instead: the same bytes in flight per CU.
+// (The plain walk kernel at 64-wide activations keeps no row of the hop-1 heads' activations -- layer 1 needs only
+// their mean, which is summed as the tiles finish: sum_rows() -- so twelve waves fit where the rows allowed eight.)
+constexpr bool sum_rows(int hh1, bool save, bool sub) { return hh1 >= 32 && !save && !sub; }
+// (128-wide features: the weights take half of LDS, eight waves are all that fit)
+constexpr int max_waves(int hh1, int fmax) { return hh1 >= 32 ? (fmax > 64 ? 8 : 12) : 16; }
 constexpr int heads_in_flight(int hh1) { return hh1 >= 32 ? 2 : 1; }
 // Subtree mode: twelve waves (three per SIMD, 170 registers each).  At sixteen the group loop spills 39 vector
 // registers, and the spill traffic costs more than the four extra waves hide (588 against 528 us per launch on
@@ -47,7 +51,7 @@ constexpr int heads_in_flight(int hh1) { return hh1 >= 32 ? 2 : 1; }
 constexpr int sub_waves(int hh1) { return hh1 >= 32 ? 8 : 12; }
 // The saving form (training) likewise: 31 spilled vector registers at sixteen waves, none at twelve (training step
 // 194 -> 189 us on the default workload); the plain walk kernel has none at sixteen and is faster there.
-constexpr int block_waves(int hh1, bool save, bool sub) { return (save || sub) ? sub_waves(hh1) : max_waves(hh1); }
+constexpr int block_waves(int hh1, bool save, bool sub, int fmax) { return (save || sub) ? sub_waves(hh1) : max_waves(hh1, fmax); }
 constexpr int kUnroll = 10;              // row loads in flight per lane in the mean phase
 constexpr int kChunks = 4;               // 64-slot chunks sampled per pass
 constexpr int kGroup = 8;                // subtree mode: roots a wavefront takes together
@@ -98,10 +102,10 @@ struct Sage2Shape {
     static constexpr int W0_FLOATS = 2 * (FU + FI) * HH1;
     static constexpr int W1_FLOATS = 2 * H1 * HH2;          // a block serves one side: one layer-1 weight set
     static constexpr int B_FLOATS = 2 * H1 + H2;
-    // roots: 0 for whole walks, kGroup in subtree mode
-    static size_t lds_bytes(int n0, int n1, int waves, int roots = 0) {
+    // roots: 0 for whole walks, kGroup in subtree mode; summed: the heads' activation rows are not kept
+    static size_t lds_bytes(int n0, int n1, int waves, int roots = 0, bool summed = false) {
         const int ids = ((roots ? roots : 1) * (n0 + n0 * n1) + 3) & ~3;
-        const int h1_rows = roots ? roots : 1 + n0;          // subtree mode keeps the roots' rows only
+        const int h1_rows = roots ? roots : summed ? 1 : 1 + n0;   // subtree mode keeps the roots' rows only
         return (size_t)(W0_FLOATS + W1_FLOATS + B_FLOATS + waves * (16 * LDA + h1_rows * LDH + ids)) * sizeof(float);
     }
 };
@@ -202,6 +206,10 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     constexpr int RP_O = 64 / FOV, NPASS_O = 16 / RP_O;     // own rows per load instruction / passes per tile
     constexpr int GN_T = 64 / FTV;                           // lane groups summing children rows
     float4 rootsum = make_float4(0.f, 0.f, 0.f, 0.f);        // partial sum of the hop-1 rows, for the root's mean
+    constexpr bool SUMROWS = sum_rows(HH1, SAVE, false);
+    float hsum_s[NT1], hsum_n[NT1];                          // SUMROWS: this lane's part (rows 4q .. 4q+3 of every tile, column
+#pragma unroll                                               // ct*16 + r of either half) of the sum of the heads' activations
+    for (int ct = 0; ct < NT1; ++ct) { hsum_s[ct] = 0.f; hsum_n[ct] = 0.f; }
     const int rounds = (n1 + kUnroll - 1) / kUnroll;
     const int per = (n1 + rounds - 1) / rounds;
     for (int j0 = 0; j0 < n0; j0 += 16) {
@@ -295,8 +303,15 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
                 float *dst = H1t + (1 + j0 + row) * LDH;
 #pragma unroll
                 for (int ct = 0; ct < NT1; ++ct) {
-                    dst[ct * 16 + r] = fmaxf(acc_s[ct][i] + b0_O[ct * 16 + r], 0.f);
-                    dst[HH1 + ct * 16 + r] = fmaxf(acc_n[ct][i] + b0_O[HH1 + ct * 16 + r], 0.f);
+                    const float vs = fmaxf(acc_s[ct][i] + b0_O[ct * 16 + r], 0.f);
+                    const float vn = fmaxf(acc_n[ct][i] + b0_O[HH1 + ct * 16 + r], 0.f);
+                    if (SUMROWS) {           // layer 1 reads only the mean of these rows: summed here, never stored
+                        hsum_s[ct] += vs;
+                        hsum_n[ct] += vn;
+                    } else {
+                        dst[ct * 16 + r] = vs;
+                        dst[HH1 + ct * 16 + r] = vn;
+                    }
                 }
             }
         }
@@ -357,21 +372,34 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     {
         constexpr int G1 = 64 / H1V;
         const int g = lane / H1V, c = lane % H1V;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j = g; j < n0; j += G1) {
-            const float4 t = *reinterpret_cast<const float4 *>(H1t + (1 + j) * LDH + 4 * c);
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-#pragma unroll
-        for (int m = H1V; m < 64; m <<= 1) {
-            s.x += __shfl_xor(s.x, m, 64); s.y += __shfl_xor(s.y, m, 64);
-            s.z += __shfl_xor(s.z, m, 64); s.w += __shfl_xor(s.w, m, 64);
-        }
         const float d0 = (float)n0;
-        if (lane < H1V) {
-            const float4 mean = make_float4(s.x / d0, s.y / d0, s.z / d0, s.w / d0);
-            *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
-            if (SAVE) stream_store(a.sv_x_mean1[side] + (size_t)pair * H1 + 4 * lane, mean);
+        if (SUMROWS) {
+            // the four lane quarters hold the sums of different rows of the same columns
+#pragma unroll
+            for (int ct = 0; ct < NT1; ++ct) {
+                hsum_s[ct] += __shfl_xor(hsum_s[ct], 16, 64); hsum_s[ct] += __shfl_xor(hsum_s[ct], 32, 64);
+                hsum_n[ct] += __shfl_xor(hsum_n[ct], 16, 64); hsum_n[ct] += __shfl_xor(hsum_n[ct], 32, 64);
+                if (q == 0) {
+                    A[ct * 16 + r] = hsum_s[ct] / d0;
+                    A[HH1 + ct * 16 + r] = hsum_n[ct] / d0;
+                }
+            }
+        } else {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = g; j < n0; j += G1) {
+                const float4 t = *reinterpret_cast<const float4 *>(H1t + (1 + j) * LDH + 4 * c);
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+#pragma unroll
+            for (int m = H1V; m < 64; m <<= 1) {
+                s.x += __shfl_xor(s.x, m, 64); s.y += __shfl_xor(s.y, m, 64);
+                s.z += __shfl_xor(s.z, m, 64); s.w += __shfl_xor(s.w, m, 64);
+            }
+            if (lane < H1V) {
+                const float4 mean = make_float4(s.x / d0, s.y / d0, s.z / d0, s.w / d0);
+                *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
+                if (SAVE) stream_store(a.sv_x_mean1[side] + (size_t)pair * H1 + 4 * lane, mean);
+            }
         }
         if (SAVE) {
             // layer-0 activations: the root's row, then the hop-1 heads' rows as one contiguous block (LDH == H1)
@@ -767,7 +795,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
 }
 
 template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB, bool DROP = false>
-__global__ __launch_bounds__(block_waves(HH1, SAVE, SUB) * 64)
+__global__ __launch_bounds__(block_waves(HH1, SAVE, SUB, FU > FI ? FU : FI) * 64)
 void sage2_kernel(const Sage2Args a) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     constexpr int H1 = S::H1, H2 = S::H2, LDA = S::LDA, LDH = S::LDH;
@@ -895,9 +923,10 @@ template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB = fals
 int launch_one(const Sage2Args &a, hipStream_t stream) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     constexpr int roots = SUB ? kGroup : 0;
-    int waves = block_waves(HH1, SAVE, SUB);                          // as many waves per CU as the LDS budget admits
-    while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves, roots) > kLdsMax) waves -= 2;
-    const size_t lds = S::lds_bytes(a.n0, a.n1, waves, roots);
+    constexpr bool summed = sum_rows(HH1, SAVE, SUB);
+    int waves = block_waves(HH1, SAVE, SUB, S::FMAX);                 // as many waves per CU as the LDS budget admits
+    while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves, roots, summed) > kLdsMax) waves -= 2;
+    const size_t lds = S::lds_bytes(a.n0, a.n1, waves, roots, summed);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
     auto kern = sage2_kernel<FU, FI, HH1, HH2, BUF, SAVE, SUB, DROP>;
     if (lds > 64 * 1024) {
@@ -906,7 +935,9 @@ int launch_one(const Sage2Args &a, hipStream_t stream) {
     }
     long long blocks = 2 * ((a.n_pairs + waves - 1) / waves);   // even blocks: user roots, odd: item roots
     if (blocks > 256) blocks = 256;                      // one block per CU, waves loop over walks
-    gs::launch_timed(kern, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, a);
+    Sage2Args b = a;
+    if (summed) b.h1_rows = 1;
+    gs::launch_timed(kern, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, b);
     return gs::check_launch("gs_sage2_forward");
 }
 
