@@ -1,4 +1,4 @@
-"""One rank of the data-parallel training rehearsal on a GPU (started by tests/test_gpu_distributed.py, never
+"""One rank of the data-parallel training rehearsal on a GPU (started by tests/test_zy_gpu_distributed.py, never
 collected by pytest).  RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment; every rank uses
 device 0 (the ranks of a one-GPU box share it, which is why the backend is gloo).
 
@@ -141,7 +141,7 @@ def main():
     args = ap.parse_args()
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     import faulthandler
-    faulthandler.dump_traceback_later(240, exit=True)
+    faulthandler.dump_traceback_later(120, exit=True)          # a stall: say where, and end (the test's deadline is 150 s)
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
     if args.backend == 'nccl':

@@ -32,26 +32,42 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(world, out_dir, extra=(), timeout=280, backend='gloo'):
+def _launch(world, out_dir, extra=(), timeout=150, backend='gloo'):
+    """Starts ``world`` ranks and waits for all of them.  A rank that ends badly ends the others at once (they
+    would sit in a collective until its timeout), and the whole launch has a deadline: a stall fails this test
+    with what the ranks printed instead of holding up the suite."""
+    import tempfile
+    import time
     port = _free_port()
-    procs = []
+    procs, logs = [], []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        log = tempfile.TemporaryFile(mode='w+')
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, WORKER, '--out', str(out_dir), '--steps', str(STEPS), '--batch', str(B),
                                        '--backend', backend] + list(extra), env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=timeout)[0])
-        except subprocess.TimeoutExpired:
+                                      stdout=log, stderr=subprocess.STDOUT, text=True))
+
+    def output(i):
+        logs[i].seek(0)
+        return logs[i].read()[-3000:]
+
+    deadline = time.monotonic() + timeout
+    while any(p.poll() is None for p in procs):
+        bad = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.monotonic() > deadline:
             for q in procs:
-                q.kill()
-            raise
-    for rank, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, "rank %d of %d failed:\n%s" % (rank, world, o[-3000:])
-    return outs
+                if q.poll() is None:
+                    q.kill()
+            for q in procs:
+                q.wait()
+            what = "rank %d of %d failed" % (bad[0], world) if bad else "no end after %d s" % timeout
+            raise AssertionError(what + ":\n" + "\n----\n".join(output(i) for i in range(world)))
+        time.sleep(0.05)
+    for rank, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d of %d failed:\n%s" % (rank, world, output(rank))
+    return [output(i) for i in range(world)]
 
 
 @pytest.fixture(scope='module')
@@ -154,9 +170,9 @@ def test_measured_cost_of_collective_and_update(runs):
 
 def test_bench_with_two_ranks_reports_two_ranks(cuda):
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
-    env['BENCH_WATCHDOG_S'] = '270'
+    env['BENCH_WATCHDOG_S'] = '140'
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '5',
-                          '--warmup', '3', '--train-steps', '5'], env=env, capture_output=True, text=True, timeout=290,
+                          '--warmup', '3', '--train-steps', '5'], env=env, capture_output=True, text=True, timeout=160,
                          cwd=ROOT)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith('{')]
