@@ -85,16 +85,28 @@ class FlatGradBucket:
             return self.flat
         world = dist.get_world_size(group)
         if world > 1:
-            # RCCL ("nccl") collectives are ordered on the stream like kernels.  gloo moves GPU
-            # tensors through host buffers on worker threads; fence the device on both sides of it.
-            fence = self.flat.is_cuda and dist.get_backend(group) == 'gloo'
-            if fence:
-                torch.cuda.synchronize()
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            if fence:
-                torch.cuda.synchronize()
+            self._sum_over_ranks(group)
             self.flat.div_(world)
         return self.flat
+
+    def host_copy(self, slot=0):
+        """A pinned host buffer of the bucket's size (two slots), for the gloo backend."""
+        if getattr(self, '_host', None) is None:
+            self._host = [torch.empty(self.flat.numel(), dtype=torch.float32).pin_memory() for _ in range(2)]
+        return self._host[slot]
+
+    def _sum_over_ranks(self, group):
+        """RCCL ("nccl") collectives are ordered on the stream like kernels.  gloo is a host library: the bucket
+        goes to the host, is summed there and comes back, each copy ordered with the device's work (gloo's own
+        handling of device tensors, on worker threads with streams of their own, is not relied on)."""
+        import torch.distributed as dist
+        if self.flat.is_cuda and dist.get_backend(group) == 'gloo':
+            host = self.host_copy()
+            host.copy_(self.flat)                            # waits for the gradients
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            self.flat.copy_(host, non_blocking=True)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
     def all_reduce_sum(self, group=None):
         """Sum over ranks, left undivided; returns the factor (1 / world) the
@@ -106,12 +118,7 @@ class FlatGradBucket:
         world = dist.get_world_size(group)
         if world <= 1:
             return 1.0
-        fence = self.flat.is_cuda and dist.get_backend(group) == 'gloo'
-        if fence:
-            torch.cuda.synchronize()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        if fence:
-            torch.cuda.synchronize()
+        self._sum_over_ranks(group)
         return 1.0 / world
 
 
@@ -227,7 +234,12 @@ class Trainer:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             with torch.no_grad():
                 flat = torch.cat([p.reshape(-1) for p in self.params])
-                dist.broadcast(flat, src=0, group=self.group)
+                if flat.is_cuda and dist.get_backend(self.group) == 'gloo':
+                    host = flat.cpu()                        # gloo is a host library: hand it host memory
+                    dist.broadcast(host, src=0, group=self.group)
+                    flat = host.to(flat.device)
+                else:
+                    dist.broadcast(flat, src=0, group=self.group)
                 off = 0
                 for p in self.params:
                     p.copy_(flat[off:off + p.numel()].view_as(p))
@@ -313,25 +325,34 @@ class Trainer:
         ``_apply_delayed`` needs.  The next replay may overwrite the bucket at once."""
         import torch.distributed as dist
         main = torch.cuda.current_stream()
+        scale = 1.0 / dist.get_world_size(self.group)
         if self._send is None:
             self._send = [torch.empty_like(self.bucket.flat) for _ in range(2)]
             self._coll_stream = torch.cuda.Stream()
         buf = self._send[self._n_graph_steps % 2]
+        if dist.get_backend(self.group) == 'gloo':
+            # a host library: the gradients travel as a pinned host copy, summed on gloo's threads
+            host = self.bucket.host_copy(self._n_graph_steps % 2)
+            host.copy_(self.bucket.flat)
+            work = dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return work, buf, scale, host
         buf.copy_(self.bucket.flat)
         side = self._coll_stream
         side.wait_stream(main)
-        if dist.get_backend(self.group) == 'gloo':
-            side.synchronize()                               # gloo stages device tensors through the host
         with torch.cuda.stream(side):
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return work, buf, 1.0 / dist.get_world_size(self.group)
+        return work, buf, scale, None
 
     def _apply_delayed(self, pending):
         from . import kernels
-        work, buf, scale = pending
-        with torch.cuda.stream(self._coll_stream):
+        work, buf, scale, host = pending
+        if host is not None:
             work.wait()
-        torch.cuda.current_stream().wait_stream(self._coll_stream)
+            buf.copy_(host, non_blocking=True)
+        else:
+            with torch.cuda.stream(self._coll_stream):
+                work.wait()
+            torch.cuda.current_stream().wait_stream(self._coll_stream)
         kernels.adam_step(self.opt.p_flat, buf, self.opt.m, self.opt.v, self.opt.next_rate(), self.opt.b1, self.opt.b2,
                           self.opt.eps, grad_scale=scale)
 
