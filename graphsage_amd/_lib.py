@@ -115,6 +115,24 @@ class Sage2L0Mask(_c.Structure):
     _fields_ = [('h1', _vp * 2), ('h1_mask', _vp * 2), ('input_scale', _c.c_float)]
 
 
+class Sage2BwdAll(_c.Structure):
+    """gs_sage2_bwd_all of include/gsage.h."""
+    _fields_ = [('z', _vp * 2), ('emb', _vp * 2), ('g_emb', _vp * 2),
+                ('targets', _vp), ('head_kernel', _vp), ('head_bias', _vp),
+                ('w1_self', _vp * 2), ('w1_neigh', _vp * 2),
+                ('h1', _vp * 2), ('x_mean1', _vp * 2), ('h1_mask', _vp * 2),
+                ('x_self', _vp * 2), ('x_mean', _vp * 2), ('self_ids', _vp * 2),
+                ('self_off', _i64 * 2), ('self_rows', _i64 * 2),
+                ('input_scale', _c.c_float), ('pred', _vp),
+                ('g_w0_self', _vp * 2), ('g_w0_neigh', _vp * 2), ('g_b0', _vp * 2),
+                ('g_w1_self', _vp * 2), ('g_w1_neigh', _vp * 2), ('g_b1', _vp * 2),
+                ('g_head_kernel', _vp), ('g_head_bias', _vp), ('loss', _vp)]
+
+
+SIGNATURES['gs_sage2_backward_all_supported'] = (_i32, [_i32] * 4)
+SIGNATURES['gs_sage2_backward_all_workspace'] = (_sz, [_i64, _i32, _i32, _i32])
+SIGNATURES['gs_sage2_backward_all'] = (_i32, [_c.POINTER(Sage2BwdAll), _i64, _i32, _i32, _i32, _i32, _i32, _i32,
+                                              _vp, _sz, _vp])
 SIGNATURES['gs_sage2_supported'] = (_i32, [_i32] * 6)
 SIGNATURES['gs_sage2_subtrees_supported'] = (_i32, [_i32] * 6)
 SIGNATURES['gs_sage2_forward'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32,

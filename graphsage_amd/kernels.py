@@ -535,6 +535,121 @@ def sage2_backward_tail_head(z, emb, targets, head_kernel, head_bias, w1_self, w
           'gs_sage2_backward_tail_head')
 
 
+class Sage2BackwardAll:
+    """A prepared ``gs_sage2_backward_all`` call: the whole backward pass of the two-hop model on the saved
+    tables of ``Sage2Call`` -- head and loss (when ``head`` is given), layer 1 backward, and every parameter
+    gradient -- in one launch plus one reduction.  Dicts are keyed 'user' / 'item'.
+
+    saved: z, h1, x_mean1, x_mean (layer-0 neighbor means), and either x_self (rows) or x_self = (table,
+           first node id) with self_ids; h1_mask or None (layer 0 without activation)
+    weights1 / grads: per type (w_self, w_neigh) of layer 1; grads[(layer, type)] = (g_w_self, g_w_neigh,
+           g_bias or None)
+    head: (emb dict, targets, kernel, bias, g_kernel, g_bias, pred, loss) or None, then ``g_emb`` dict at run()"""
+
+    def __init__(self, saved, weights1, grads, n0, normalize, act, head=None, input_scale=1.0):
+        lib = load()
+        types = ('user', 'item')
+        b, h2 = saved['z']['user'].shape
+        h1 = weights1['user'][0].shape[0]
+        by_id = saved.get('self_ids') is not None
+        f = saved['x_mean']['user'].shape[1]
+        rows = b * (1 + int(n0))
+        if not lib.gs_sage2_backward_all_supported(f, saved['x_mean']['item'].shape[1], h1, h2):
+            raise _lib.GsageError("gs_sage2_backward_all does not cover F=%d H1=%d H2=%d" % (f, h1, h2))
+        st = _lib.Sage2BwdAll()
+        self._keep = [saved, weights1, grads, head]
+        for i, t in enumerate(types):
+            for name, d, shape in (('z', saved['z'], (b, h2)), ('x_mean1', saved['x_mean1'], (b, h1)),
+                                   ('x_mean', saved['x_mean'], (rows, f))):
+                _dev(d[t], torch.float32, '%s[%s]' % (name, t), 2)
+                if tuple(d[t].shape) != shape:
+                    raise ValueError("%s[%s] must be %s (got %s)" % (name, t, shape, tuple(d[t].shape)))
+            _dev(saved['h1'][t], torch.float32, 'h1[%s]' % t, 2)
+            if saved['h1'][t].shape[0] < b or saved['h1'][t].shape[1] != h1:
+                raise ValueError("h1[%s] must hold at least %d rows of %d" % (t, b, h1))
+            st.z[i], st.x_mean1[i], st.x_mean[i], st.h1[i] = (ptr(saved['z'][t]), ptr(saved['x_mean1'][t]),
+                                                              ptr(saved['x_mean'][t]), ptr(saved['h1'][t]))
+            if by_id:
+                table, first = saved['x_self'][t]
+                _dev(table, torch.float32, 'feature table[%s]' % t, 2)
+                _dev(saved['self_ids'][t], torch.int32, 'self_ids[%s]' % t, 1)
+                if table.shape[1] != f or saved['self_ids'][t].numel() != rows:
+                    raise ValueError("feature table[%s] must be %d wide, self_ids[%s] must have %d entries" % (t, f, t, rows))
+                st.x_self[i], st.self_ids[i] = ptr(table), ptr(saved['self_ids'][t])
+                st.self_off[i], st.self_rows[i] = int(first), table.shape[0]
+            else:
+                _dev(saved['x_self'][t], torch.float32, 'x_self[%s]' % t, 2)
+                if tuple(saved['x_self'][t].shape) != (rows, f):
+                    raise ValueError("x_self[%s] must be %s" % (t, (rows, f)))
+                st.x_self[i] = ptr(saved['x_self'][t])
+            if saved.get('h1_mask') is not None:
+                _dev(saved['h1_mask'][t], torch.int32, 'h1_mask[%s]' % t, 1)
+                if saved['h1_mask'][t].numel() != b * int(n0) * (h1 // 32):
+                    raise ValueError("h1_mask[%s] must have %d words" % (t, b * int(n0) * (h1 // 32)))
+                st.h1_mask[i] = ptr(saved['h1_mask'][t])
+            ws, wn = weights1[t]
+            for name, w in (('w1_self', ws), ('w1_neigh', wn)):
+                _dev(w, torch.float32, '%s[%s]' % (name, t), 2)
+                if tuple(w.shape) != (h1, h2 // 2):
+                    raise ValueError("%s[%s] must be %s" % (name, t, (h1, h2 // 2)))
+            st.w1_self[i], st.w1_neigh[i] = ptr(ws), ptr(wn)
+            for layer, k, n, names in ((0, f, h1, ('g_w0_self', 'g_w0_neigh', 'g_b0')), (1, h1, h2, ('g_w1_self', 'g_w1_neigh', 'g_b1'))):
+                g_ws, g_wn, g_b = grads[(layer, t)]
+                for name, g, cnt in ((names[0], g_ws, k * (n // 2)), (names[1], g_wn, k * (n // 2)), (names[2], g_b, n)):
+                    if g is None and name.startswith('g_b'):
+                        continue
+                    _dev(g, torch.float32, '%s[%s]' % (name, t))
+                    if g.numel() != cnt:
+                        raise ValueError("%s[%s] has %d elements, %d needed" % (name, t, g.numel(), cnt))
+                    getattr(st, name)[i] = ptr(g)
+        self._head = head is not None
+        if head is not None:
+            emb, targets, kernel, bias, g_kernel, g_bias, pred, loss = head
+            for name, x, n in (('targets', targets, b), ('pred', pred, b), ('head_kernel', kernel, 2 * h2), ('head_bias', bias, 1),
+                               ('g_kernel', g_kernel, 2 * h2), ('g_bias', g_bias, 1), ('loss', loss, 1)):
+                _dev(x, torch.float32, name)
+                if x.numel() != n:
+                    raise ValueError("%s must have %d elements (got %d)" % (name, n, x.numel()))
+            for i, t in enumerate(types):
+                _dev(emb[t], torch.float32, 'emb[%s]' % t, 2)
+                if tuple(emb[t].shape) != (b, h2):
+                    raise ValueError("emb[%s] must be %s" % (t, (b, h2)))
+                st.emb[i] = ptr(emb[t])
+            st.targets, st.head_kernel, st.head_bias = ptr(targets), ptr(kernel), ptr(bias)
+            st.g_head_kernel, st.g_head_bias, st.pred, st.loss = ptr(g_kernel), ptr(g_bias), ptr(pred), ptr(loss)
+        st.input_scale = float(input_scale)
+        need = lib.gs_sage2_backward_all_workspace(b, f, h1, h2)
+        self._ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=saved['z']['user'].device)
+        self._st, self._lib = st, lib
+        self._args = (b, int(n0), f, h1, h2, int(bool(normalize)), ACT[act])
+        self._shape = (b, h2)
+        self.epoch = _storage_epoch            # the gradient views it writes belong to this parameter layout
+
+    def run(self, g_emb=None, targets=None):
+        if self.epoch != _storage_epoch:
+            raise _lib.GsageError("parameters were moved to other storage after this call was prepared; prepare it again")
+        if self._head:
+            if targets is not None:
+                _dev(targets, torch.float32, 'targets')
+                if targets.numel() != self._shape[0]:
+                    raise ValueError("targets must have %d elements" % self._shape[0])
+                self._st.targets = ptr(targets)
+                self._keep_targets = targets
+        else:
+            for i, t in enumerate(('user', 'item')):
+                _dev(g_emb[t], torch.float32, 'g_emb[%s]' % t, 2)
+                if tuple(g_emb[t].shape) != self._shape:
+                    raise ValueError("g_emb[%s] must be %s" % (t, self._shape))
+                self._st.g_emb[i] = ptr(g_emb[t])
+            self._keep_g = g_emb
+        check(self._lib.gs_sage2_backward_all(ctypes.byref(self._st), *self._args, ptr(self._ws), self._ws.numel() * 4,
+                                              stream_handle()), 'gs_sage2_backward_all')
+
+
+def sage2_backward_all_supported(fu, fi, h1, h2):
+    return bool(load().gs_sage2_backward_all_supported(int(fu), int(fi), int(h1), int(h2)))
+
+
 def tail_head_slab(b, h2, device):
     """Workspace of ``sage2_backward_tail_head`` for B pairs and H2-wide embeddings."""
     n = load().gs_sage2_tail_head_workspace(int(b), int(h2))

@@ -294,6 +294,7 @@ class Trainer:
                                                self.head.bias, self.head.kernel.grad, self.head.bias.grad,
                                                self.head.kernel.device)
         eng._wgrad_pairs = None
+        eng._bwd_all = None
         return True
 
     # -- HIP-graph replay of the step ---------------------------------------------------

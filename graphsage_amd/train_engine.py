@@ -69,6 +69,11 @@ class SageTrainEngine(SageForwardEngine):
         self._tail_kernel = self.walk_train and kernels.sage2_backward_tail_supported(m.dims[1]['user'], m.dims[2]['user'])
         self._side2 = None
         self._wgrad_pairs = None
+        # ... and, where a wavefront can keep every parameter's sum in registers, the WHOLE backward pass in one
+        # kernel and one reduction (see _backward_walks); fused_backward = False keeps the separate launches
+        self.fused_backward = bool(self._tail_kernel and kernels.sage2_backward_all_supported(
+            f['user'], f['item'], m.dims[1]['user'], m.dims[2]['user']))
+        self._bwd_all = None
         # Own rows of layer 0 are not written by the forward pass when the weight-gradient kernel can read
         # them from the feature table by node id: the forward kernel then leaves 4 bytes per row (the id)
         # instead of the row.
@@ -110,6 +115,7 @@ class SageTrainEngine(SageForwardEngine):
             self.h1_mask = None
             self._walk_train_call = None
             self._wgrad_pairs = None
+            self._bwd_all = None
 
     def _forward_walks_train(self, seeds, walk_ids, rng_seed, replay):
         m = self.model
@@ -236,9 +242,39 @@ class SageTrainEngine(SageForwardEngine):
         runs on the caller's stream, of the item side on a second, layer 1 on a
         third."""
         m = self.model
+        top = m._aggs[1]
+        relu0 = all(m._aggs[0][t].activation == 'relu' for t in _TYPES)
+        if self.fused_backward and self._tail_kernel and (self.h1_mask is not None or not relu0):
+            # everything above in ONE launch, the weight gradients of both layers and the head's with it; one
+            # reduction of the blocks' partial sums follows
+            key = (kernels.storage_epoch(), head is not None, None if head is None else tuple(x.data_ptr() for x in head[:2] + head[3:]))
+            if self._bwd_all is None or self._bwd_all[0] != key:
+                rows = {t: self.h[0][t].shape[0] for t in _TYPES}
+                saved = {'z': self.z, 'h1': self.h[0], 'x_mean1': {t: self.x_mean[1][t][:self.batch] for t in _TYPES},
+                         'x_mean': {t: self.x_mean[0][t][:rows[t]] for t in _TYPES}, 'h1_mask': self.h1_mask}
+                if self.self_ids is not None:
+                    saved['x_self'], saved['self_ids'] = {t: self.tables[t] for t in _TYPES}, self.self_ids
+                else:
+                    saved['x_self'] = self.x_self
+                grads = {(layer, t): self._grads_of(m._aggs[layer][t]) for layer in (0, 1) for t in _TYPES}
+                hd = None
+                if head is not None:
+                    head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss = head
+                    hd = ({'user': self.emb_all[:self.batch], 'item': self.emb_all[self.batch:]}, targets, head_kernel,
+                          head_bias, g_kernel, g_bias, pred, loss)
+                call = kernels.Sage2BackwardAll(saved, {t: (top[t].w_self, top[t].w_neigh) for t in _TYPES}, grads,
+                                                self.fanouts[0], m.normalize == "l2", top['user'].activation, head=hd,
+                                                input_scale=1.0 / (1.0 - self.dropout) if self.dropout else 1.0)
+                self._bwd_all = (key, call)
+            if head is not None:
+                self._bwd_all[1].run(targets=head[2])
+            else:
+                self._bwd_all[1].run(g_emb={'user': g_user.contiguous(), 'item': g_item.contiguous()})
+            if self._padded_model is not None:
+                self._padded_model.scatter_grads()
+            return
         if self._side2 is None:
             self._side2 = torch.cuda.Stream()
-        top = m._aggs[1]
         l0_mask = None if self.h1_mask is None else {'h1': self.h[0], 'h1_mask': self.h1_mask}
         if self.dropout:
             l0_mask['input_scale'] = 1.0 / (1.0 - self.dropout)

@@ -616,6 +616,52 @@ int gs_link_head_reduce(const void *slab, int n_rows, int E, int64_t B, float *g
                         float *loss, void *stream);
 
 /*
+ * The WHOLE backward pass of the two-hop model on the tables gs_sage2_forward saved, in one launch plus one
+ * reduction (train_movielens.py:183-189: loss, gradients of every trainable weight): what
+ * gs_sage2_backward_tail_head computes (head, loss, l2 normalisation and layer 1 backward, models.py:32,
+ * utils.py:103-119), and with it the parameter gradients of the head, of layer 1 and of layer 0 for both node
+ * types -- the work of gs_link_head_reduce and of two gs_sage_project_wgrad_pair calls.  Neither g_z nor
+ * g_h1 passes through memory: the gradient rows of a walk's n0 hop-1 heads are one vector under n0 relu masks,
+ * so the layer-0 weight gradients need only the saved input rows and one mask word per row.
+ *   z, emb, h1, x_mean1, x_mean, h1_mask: the gs_sage2_saved tables / the forward's output, per node type
+ *   x_self, self_ids, self_off, self_rows: the own rows of layer 0 [n_pairs * (1 + n0), F], or -- with
+ *       self_ids [n_pairs * (1 + n0)] -- the feature TABLE of the type (self_rows rows, the first holding node
+ *       self_off), read by id (ids outside the table count as rows of zeros), for both types or for none
+ *   h1_mask NULL (both): layer 0 has NO activation.  Otherwise layer 0 is relu, the hop-1 heads' masks are the
+ *       words, the roots' masks are read off h1 (> 0)
+ *   targets != NULL: the link head (head_kernel [2 H2], head_bias [1]) and the mean-squared-error loss are
+ *       evaluated here (pred [n_pairs], g_head_kernel [2 H2], g_head_bias [1], loss [1] are written; emb is
+ *       read); targets == NULL: the embeddings' gradients are g_emb [n_pairs, H2] and the head fields are ignored
+ *   input_scale: 0 or 1 none; else dropout's 1 / (1 - rate) as in gs_sage2_l0_mask
+ *   g_w0_self / g_w0_neigh [F, H1/2], g_b0 [H1] (nullable), g_w1_self / g_w1_neigh [H1, H2/2], g_b1 [H2]
+ *       (nullable): overwritten
+ * act is layer 1's activation, normalize as in gs_sage2_forward.  Partial sums leave the first launch as
+ * one row per block in `workspace` (gs_sage2_backward_all_workspace bytes) and are added in row order:
+ * bitwise reproducible.  Shapes: gs_sage2_backward_all_supported() != 0 (both feature widths F = 32 or 64,
+ * H1 = H2 = 32: a wavefront keeps every sum in registers), else GS_ELIMIT.
+ */
+typedef struct gs_sage2_bwd_all {
+    const float *z[2], *emb[2], *g_emb[2];
+    const float *targets, *head_kernel, *head_bias;
+    const float *w1_self[2], *w1_neigh[2];
+    const float *h1[2], *x_mean1[2];
+    const uint32_t *h1_mask[2];
+    const float *x_self[2], *x_mean[2];
+    const int32_t *self_ids[2];
+    int64_t self_off[2], self_rows[2];
+    float input_scale;
+    float *pred;
+    float *g_w0_self[2], *g_w0_neigh[2], *g_b0[2];
+    float *g_w1_self[2], *g_w1_neigh[2], *g_b1[2];
+    float *g_head_kernel, *g_head_bias, *loss;
+} gs_sage2_bwd_all;
+
+int gs_sage2_backward_all_supported(int Fu, int Fi, int H1, int H2);
+size_t gs_sage2_backward_all_workspace(int64_t n_pairs, int F, int H1, int H2);
+int gs_sage2_backward_all(const gs_sage2_bwd_all *p, int64_t n_pairs, int n0, int F, int H1, int H2,
+                          int normalize, int act, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Link head of the reference's training script: concat(user_emb, item_emb) ->
  * Dense(1, sigmoid) (link_utils.py:167-168,244-247 as used at
  * train_movielens.py:179), kernel device float[2E], bias device float[1].

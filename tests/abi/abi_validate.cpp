@@ -306,6 +306,49 @@ int main() {
     REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, nullptr, f, f, 8, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th, nullptr, nullptr));
     REFUSED(GS_EINVAL, gs_sage2_backward_tail_head(f, f, f, f, f, f, f, 4096, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, f, arena, th - 4, nullptr, nullptr));
 
+    // ---- the whole two-hop backward pass in one launch ----
+    EXPECT(gs_sage2_backward_all_supported(64, 64, 32, 32) == 1 && gs_sage2_backward_all_supported(32, 32, 32, 32) == 1);
+    EXPECT(gs_sage2_backward_all_supported(64, 32, 32, 32) == 0 && gs_sage2_backward_all_supported(64, 64, 64, 32) == 0 &&
+           gs_sage2_backward_all_supported(64, 64, 32, 64) == 0 && gs_sage2_backward_all_supported(128, 128, 32, 32) == 0);
+    EXPECT(gs_sage2_backward_all_workspace(0, 64, 32, 32) == 0 && gs_sage2_backward_all_workspace(4096, 128, 32, 32) == 0);
+    const size_t ba = gs_sage2_backward_all_workspace(4096, 64, 32, 32);
+    EXPECT(ba == ((size_t)256 * (2 * (2 * 64 * 16 + 32) + 2 * (2 * 32 * 16 + 32) + 66) + (size_t)2 * 4096 * 32) * 4);
+    EXPECT(gs_sage2_backward_all_workspace(3, 32, 32, 32) == ((size_t)1 * (2 * (2 * 32 * 16 + 32) + 2 * (2 * 32 * 16 + 32) + 66) + 2 * 3 * 32) * 4);
+    {
+        gs_sage2_bwd_all p{};
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(nullptr, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 0, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 0, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, 8, 25, 128, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, 8, 25, 64, 32, 64, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, 77, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));   // null tables
+        for (int t = 0; t < 2; ++t) {
+            p.z[t] = p.w1_self[t] = p.w1_neigh[t] = p.h1[t] = p.x_mean1[t] = p.x_self[t] = p.x_mean[t] = f;
+            p.g_emb[t] = f;
+        }
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 4096, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba - 4, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, nullptr, ba, nullptr));
+        p.g_emb[1] = nullptr;
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        p.g_emb[1] = f;
+        p.targets = f;                                           // the head form: emb, head weights and outputs are needed
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        p.emb[0] = p.emb[1] = f;
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        p.targets = nullptr;
+        p.self_ids[0] = i32;                                     // ids for one node type only
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        p.self_ids[1] = i32;                                     // ids without the table's row count
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        p.self_ids[0] = p.self_ids[1] = nullptr;
+        p.h1_mask[1] = reinterpret_cast<const uint32_t *>(f);    // mask words for one node type only
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        p.h1_mask[1] = nullptr;
+        p.x_mean[0] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(f) + 4);   // not 16-byte aligned
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+    }
+
     // ---- link head, optimizer, staging ----
     EXPECT(gs_link_head_workspace(-1, 32) == 0 && gs_link_head_workspace(4096, 32) == (size_t)256 * 66 * 4);
     ACCEPTED(gs_link_head_fwd(nullptr, nullptr, 0, 32, nullptr, nullptr, nullptr, nullptr));

@@ -585,6 +585,39 @@ def test_plan_backward_with_and_without_the_tail_kernel(cuda):
     assert float((grads[0][1] - grads[1][1]).abs().max()) <= 2e-6 * scale
 
 
+@pytest.mark.parametrize('b,ns,f,rate,bias,normalize', [(40, [6, 3], 64, 0.0, True, True), (130, [25, 10], 64, 0.0, True, True),
+                                                        (7, [1, 2], 32, 0.0, True, True), (48, [4, 2], 32, 0.0, False, False),
+                                                        (33, [9, 2], 64, 0.25, True, True), (2100, [5, 2], 64, 0.0, True, True)])
+def test_whole_backward_in_one_kernel_equals_the_separate_launches(cuda, b, ns, f, rate, bias, normalize):
+    """A two-hop training step with the whole backward pass in one kernel (head, layer 1, every weight
+    gradient; one reduction after it) and with the separate launches (top of the backward pass, paired weight
+    gradients per layer, their reductions): same loss, same gradients up to the order of the sums, and the
+    one-kernel form gives the same bits when it runs again."""
+    from graphsage_amd.train import LinkHead
+    g, links, targets = _toy(5, fu=f, fi=f)
+    pick = np.arange(b) % len(links)                       # (more pairs than links: links repeat, walks still differ)
+    sizes = [32, 32]
+    grads = []
+    for fused in (True, False, True):
+        gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+        model = ga.GraphSAGE(sizes, gen, seed=11, bias=bias, normalize='l2' if normalize else None, dropout=rate)
+        model.build()
+        tr = Trainer(model, head=LinkHead(sizes[-1], cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
+        assert tr.engine.tail_kernel and tr.engine.fused_backward
+        tr.engine.fused_backward = fused
+        lk = np.asarray(links)[pick]
+        seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+        loss, pred = tr.step_device(seeds, torch.from_numpy(targets[pick]).to(cuda),
+                                    torch.arange(2 * b, dtype=torch.int64, device=cuda), rng_seed=9)
+        grads.append((float(loss), tr.bucket.flat.clone(), pred.clone()))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * max(1.0, abs(grads[1][0]))
+    assert float((grads[0][2] - grads[1][2]).abs().max()) < 1e-6     # (the same arithmetic, contracted differently)
+    scale = float(grads[1][1].abs().max())
+    assert scale > 0
+    assert float((grads[0][1] - grads[1][1]).abs().max()) <= 2e-6 * scale
+    assert grads[0][0] == grads[2][0] and torch.equal(grads[0][1], grads[2][1])
+
+
 def test_stage_batch_copies_inputs_and_rate_in_one_launch(cuda):
     from graphsage_amd import kernels
     gen = torch.Generator(device=cuda).manual_seed(1)
