@@ -129,10 +129,17 @@ class Sage2BwdAll(_c.Structure):
                 ('g_head_kernel', _vp), ('g_head_bias', _vp), ('loss', _vp)]
 
 
+class AdamUpdate(_c.Structure):
+    """gs_adam_update of include/gsage.h."""
+    _fields_ = [('grads', _vp), ('params', _vp), ('m', _vp), ('v', _vp), ('n', _i64), ('lr_t_device', _vp),
+                ('lr_t', _c.c_float), ('beta_1', _c.c_float), ('beta_2', _c.c_float), ('epsilon', _c.c_float),
+                ('grad_scale', _c.c_float)]
+
+
 SIGNATURES['gs_sage2_backward_all_supported'] = (_i32, [_i32] * 4)
 SIGNATURES['gs_sage2_backward_all_workspace'] = (_sz, [_i64, _i32, _i32, _i32])
 SIGNATURES['gs_sage2_backward_all'] = (_i32, [_c.POINTER(Sage2BwdAll), _i64, _i32, _i32, _i32, _i32, _i32, _i32,
-                                              _vp, _sz, _vp])
+                                              _vp, _sz, _c.POINTER(AdamUpdate), _vp])
 SIGNATURES['gs_sage2_supported'] = (_i32, [_i32] * 6)
 SIGNATURES['gs_sage2_subtrees_supported'] = (_i32, [_i32] * 6)
 SIGNATURES['gs_sage2_forward'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32,

@@ -102,6 +102,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// One element of Adam (the TF2 form: p -= lr_t * m / (sqrt(v) + eps)).  Written once and without contraction
+// into fused multiply-adds, so that every kernel that applies it gives the same bits.
+__device__ __forceinline__ void adam_element(float &p, float &m, float &v, float g, float lr_t, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    const float mi = b1 * m + (1.f - b1) * g;
+    const float vi = b2 * v + (1.f - b2) * g * g;
+    m = mi;
+    v = vi;
+    p -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
 // Dropout of the aggregator inputs (models.py:152,165), addressed like the sampling draws: the four columns
 // 4*c4 .. 4*c4+3 of row `row` of input `site` of walk `walk` are kept where the four words of
 // Philox(counter = (walk lo, walk hi, kDropSite | site, row * 64 + c4), key = dropout seed) are >= threshold

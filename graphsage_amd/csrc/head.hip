@@ -115,12 +115,7 @@ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__re
                  float grad_scale) {
     const float lr_t = lr_dev ? lr_dev[0] : lr_arg;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-        const float gi = g[i] * grad_scale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        gs::adam_element(p[i], m[i], v[i], g[i] * grad_scale, lr_t, b1, b2, eps);
     }
 }
 

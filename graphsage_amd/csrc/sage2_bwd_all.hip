@@ -409,12 +409,20 @@ struct Segment {
     int begin, end;
     float *dst;
     float scale;
+    int update;                              // the optimizer step follows for these elements
+};
+// Adam on the elements just summed (the arithmetic of gs_adam_step, element by element)
+struct AdamArgs {
+    const float *g_base, *lr_dev;
+    float *p, *m, *v;
+    float lr, b1, b2, eps, g_scale;
 };
 constexpr int kSegments = 16;
 struct ReduceArgs {
     Segment seg[kSegments];
     int n_seg, n_rows, row_floats;
     const float *slab;
+    AdamArgs adam;
 };
 
 __global__ __launch_bounds__(256)
@@ -440,7 +448,16 @@ void sage2_bwd_reduce_kernel(const ReduceArgs a) {
         for (int g = 0; g < 8; ++g) s += part[g * 32 + threadIdx.x];
         for (int i = 0; i < a.n_seg; ++i)
             if (e >= a.seg[i].begin && e < a.seg[i].end) {
-                if (a.seg[i].dst) a.seg[i].dst[e - a.seg[i].begin] = s * a.seg[i].scale;
+                if (a.seg[i].dst) {
+                    float *dst = a.seg[i].dst + (e - a.seg[i].begin);
+                    const float g = s * a.seg[i].scale;
+                    *dst = g;
+                    if (a.seg[i].update) {
+                        const long long at = dst - a.adam.g_base;
+                        const float lr_t = a.adam.lr_dev ? a.adam.lr_dev[0] : a.adam.lr;
+                        gs::adam_element(a.adam.p[at], a.adam.m[at], a.adam.v[at], g * a.adam.g_scale, lr_t, a.adam.b1, a.adam.b2, a.adam.eps);
+                    }
+                }
                 break;
             }
     }
@@ -472,7 +489,8 @@ extern "C" size_t gs_sage2_backward_all_workspace(int64_t n_pairs, int F, int H1
 }
 
 extern "C" int gs_sage2_backward_all(const gs_sage2_bwd_all *p, int64_t n_pairs, int n0, int F, int H1, int H2,
-                                     int normalize, int act, void *workspace, size_t workspace_bytes, void *stream) {
+                                     int normalize, int act, void *workspace, size_t workspace_bytes,
+                                     const gs_adam_update *adam, void *stream) {
     const char *who = "gs_sage2_backward_all";
     if (!p) return gs::fail(GS_EINVAL, "%s: null argument block", who);
     if (n_pairs < 1 || n0 < 1) return gs::fail(GS_EINVAL, "%s: n_pairs=%lld n0=%d", who, (long long)n_pairs, n0);
@@ -518,6 +536,38 @@ extern "C" int gs_sage2_backward_all(const gs_sage2_bwd_all *p, int64_t n_pairs,
     a.root_g[0] = a.slab + (size_t)all_blocks(n_pairs) * slab_floats(F, H2);
     a.root_g[1] = a.root_g[0] + (size_t)n_pairs * kH1;
     const int64_t blocks = all_blocks(n_pairs);
+    // where the stretches of a slab row go
+    ReduceArgs ra{};
+    const int HH2 = H2 / 2, L0 = 2 * F * 16 + 32, W1 = 2 * kH1 * HH2;
+    int n = 0;
+    bool outside = false;                    // a gradient that does not lie in the optimizer's flat buffer
+    auto seg = [&](int begin, int len, float *dst, float scale, bool param = true) {
+        const bool upd = adam && dst && param;
+        if (upd && (dst < adam->grads || dst + len > adam->grads + adam->n)) outside = true;
+        ra.seg[n++] = Segment{begin, begin + len, dst, scale, upd ? 1 : 0};
+    };
+    for (int t = 0; t < 2; ++t) {
+        seg(t * L0, F * 16, p->g_w0_self[t], 1.f);
+        seg(t * L0 + F * 16, F * 16, p->g_w0_neigh[t], 1.f);
+        seg(t * L0 + 2 * F * 16, 32, p->g_b0[t], 1.f);
+    }
+    for (int t = 0; t < 2; ++t) seg(2 * L0 + t * H2, H2, p->g_b1[t], 1.f);
+    const int hd = 2 * L0 + 2 * H2;
+    seg(hd, 2 * H2, head ? p->g_head_kernel : nullptr, 1.f);
+    seg(hd + 2 * H2, 1, head ? p->g_head_bias : nullptr, 1.f);
+    seg(hd + 2 * H2 + 1, 1, head ? p->loss : nullptr, 1.f / (float)n_pairs, false);
+    for (int t = 0; t < 2; ++t) {
+        const int at = hd + 2 * H2 + 2 + t * W1;
+        seg(at, kH1 * HH2, p->g_w1_self[t], 1.f);
+        seg(at + kH1 * HH2, kH1 * HH2, p->g_w1_neigh[t], 1.f);
+    }
+    if (adam) {
+        if (!adam->grads || !adam->params || !adam->m || !adam->v || adam->n < 1)
+            return gs::fail(GS_EINVAL, "%s: adam needs grads, params, m, v and n > 0", who);
+        if (outside) return gs::fail(GS_EINVAL, "%s: with adam every gradient pointer must lie inside adam->grads[0 .. n)", who);
+        ra.adam = AdamArgs{adam->grads, adam->lr_t_device, adam->params, adam->m, adam->v,
+                           adam->lr_t, adam->beta_1, adam->beta_2, adam->epsilon, adam->grad_scale};
+    }
     hipStream_t s = (hipStream_t)stream;
     bool launched = false;
 #define GS_ALL(f, hh2, u)                                                                                           \
@@ -539,26 +589,6 @@ extern "C" int gs_sage2_backward_all(const gs_sage2_bwd_all *p, int64_t n_pairs,
     if (!launched) return gs::fail(GS_ELIMIT, "%s: no kernel for F=%d H2=%d", who, F, H2);
     if (int rc = gs::check_launch(who)) return rc;
 
-    // where the stretches of a slab row go
-    ReduceArgs ra{};
-    const int HH2 = H2 / 2, L0 = 2 * F * 16 + 32, W1 = 2 * kH1 * HH2;
-    int n = 0;
-    auto seg = [&](int begin, int len, float *dst, float scale) { ra.seg[n++] = Segment{begin, begin + len, dst, scale}; };
-    for (int t = 0; t < 2; ++t) {
-        seg(t * L0, F * 16, p->g_w0_self[t], 1.f);
-        seg(t * L0 + F * 16, F * 16, p->g_w0_neigh[t], 1.f);
-        seg(t * L0 + 2 * F * 16, 32, p->g_b0[t], 1.f);
-    }
-    for (int t = 0; t < 2; ++t) seg(2 * L0 + t * H2, H2, p->g_b1[t], 1.f);
-    const int hd = 2 * L0 + 2 * H2;
-    seg(hd, 2 * H2, head ? p->g_head_kernel : nullptr, 1.f);
-    seg(hd + 2 * H2, 1, head ? p->g_head_bias : nullptr, 1.f);
-    seg(hd + 2 * H2 + 1, 1, head ? p->loss : nullptr, 1.f / (float)n_pairs);
-    for (int t = 0; t < 2; ++t) {
-        const int at = hd + 2 * H2 + 2 + t * W1;
-        seg(at, kH1 * HH2, p->g_w1_self[t], 1.f);
-        seg(at + kH1 * HH2, kH1 * HH2, p->g_w1_neigh[t], 1.f);
-    }
     ra.n_seg = n; ra.n_rows = (int)blocks; ra.row_floats = slab_floats(F, H2); ra.slab = a.slab;
     hipLaunchKernelGGL(sage2_bwd_reduce_kernel, dim3((unsigned)((ra.row_floats + 31) / 32)), dim3(256), 0, s, ra);
     return gs::check_launch("gs_sage2_backward_all (reduce)");

@@ -625,7 +625,10 @@ class Sage2BackwardAll:
         self._shape = (b, h2)
         self.epoch = _storage_epoch            # the gradient views it writes belong to this parameter layout
 
-    def run(self, g_emb=None, targets=None):
+    def run(self, g_emb=None, targets=None, adam=None):
+        """adam: None, or a dict for the optimizer step in the same reduction: grads, params, m, v (flat float32
+        buffers; every gradient this call writes must be a view into ``grads``), b1, b2, eps, and the rate as
+        'lr' (a float) or 'lr_dev' (a one-element tensor, for captured graphs); optional grad_scale."""
         if self.epoch != _storage_epoch:
             raise _lib.GsageError("parameters were moved to other storage after this call was prepared; prepare it again")
         if self._head:
@@ -642,8 +645,22 @@ class Sage2BackwardAll:
                     raise ValueError("g_emb[%s] must be %s" % (t, self._shape))
                 self._st.g_emb[i] = ptr(g_emb[t])
             self._keep_g = g_emb
+        upd = None
+        if adam is not None:
+            for name in ('grads', 'params', 'm', 'v'):
+                _dev(adam[name], torch.float32, 'adam[%s]' % name, 1)
+                if adam[name].numel() != adam['grads'].numel():
+                    raise ValueError("adam[%s] must have %d elements" % (name, adam['grads'].numel()))
+            lr_dev = adam.get('lr_dev')
+            if lr_dev is not None:
+                _dev(lr_dev, torch.float32, 'adam[lr_dev]')
+            self._adam = _lib.AdamUpdate(ptr(adam['grads']), ptr(adam['params']), ptr(adam['m']), ptr(adam['v']),
+                                         adam['grads'].numel(), ptr(lr_dev), float(adam.get('lr', 0.0)), float(adam['b1']),
+                                         float(adam['b2']), float(adam['eps']), float(adam.get('grad_scale', 1.0)))
+            self._keep_adam = adam
+            upd = ctypes.byref(self._adam)
         check(self._lib.gs_sage2_backward_all(ctypes.byref(self._st), *self._args, ptr(self._ws), self._ws.numel() * 4,
-                                              stream_handle()), 'gs_sage2_backward_all')
+                                              upd, stream_handle()), 'gs_sage2_backward_all')
 
 
 def sage2_backward_all_supported(fu, fi, h1, h2):

@@ -192,6 +192,7 @@ class Trainer:
             raise ValueError("overlap must be 'none', 'capture' or 'delayed'")
         self.overlap = overlap
         self._collective_always = bool(collective_at_world_one)
+        self.fuse_update = True                              # let the backward pass apply the optimizer step where it can
         self._pending = None                                 # delayed mode: (work, buffer, 1 / world) of the last step
         self._send = None
         self._coll_stream = None
@@ -259,14 +260,37 @@ class Trainer:
         self._prepare_head_step()
         # every gradient of the bucket is overwritten by this step's kernels: no zeroing pass
         emb_u, emb_i = eng.forward_train(seeds, walk_ids, rng_seed)
-        loss, pred = self._head_and_backward(emb_u, emb_i, targets)
-        self.opt.step(grad_scale=self.bucket.all_reduce_sum(self.group))
+        if not self._ranks()[0] and self._update_in_backward():
+            # one process: nothing stands between the gradients and the update, the backward pass applies it
+            loss, pred = self._head_and_backward(emb_u, emb_i, targets, self._adam_args(lr=self.opt.next_rate()))
+        else:
+            loss, pred = self._head_and_backward(emb_u, emb_i, targets)
+            self.opt.step(grad_scale=self.bucket.all_reduce_sum(self.group))
         return loss, pred.reshape(-1, 1)
 
-    def _head_and_backward(self, emb_u, emb_i, targets):
+    def _update_in_backward(self):
+        eng = self.engine
+        return bool(self.fuse_update and eng is not None and eng.tail_kernel and self.opt.p_flat is not None
+                    and eng.can_update_in_backward(self.bucket.flat, (self.head.kernel.grad, self.head.bias.grad)))
+
+    def _adam_args(self, lr=None, lr_dev=None):
+        o = self.opt
+        d = {'grads': self.bucket.flat, 'params': o.p_flat, 'm': o.m, 'v': o.v, 'b1': o.b1, 'b2': o.b2, 'eps': o.eps}
+        if lr_dev is not None:
+            d['lr_dev'] = lr_dev
+        else:
+            d['lr'] = lr
+        return d
+
+    def _head_and_backward(self, emb_u, emb_i, targets, adam=None):
         """Head + loss + the engine's backward pass; on the two-hop route the head is evaluated inside
-        the first kernel of the backward pass instead of two launches of its own."""
+        the first kernel of the backward pass instead of two launches of its own.  ``adam``: the optimizer
+        step as well (``_adam_args``; only when ``_update_in_backward()``)."""
         eng, hs = self.engine, self._head_step
+        if adam is not None:
+            eng.backward_head(self.head.kernel, self.head.bias, targets, self.head.kernel.grad, self.head.bias.grad,
+                              hs.pred, hs.loss, adam=adam)
+            return hs.loss, hs.pred
         if eng.tail_kernel:
             if not (isinstance(targets, torch.Tensor) and targets.is_cuda and targets.dtype == torch.float32
                     and targets.is_contiguous() and targets.numel() == eng.batch):
@@ -311,6 +335,9 @@ class Trainer:
         from . import kernels
         eng = self.engine
         emb_u, emb_i = eng.forward_train(eng.seeds_buf, self._walk_buf, self._graph_seed)
+        if with_update and not with_collective and self._update_in_backward():
+            self._head_and_backward(emb_u, emb_i, self._target_buf, self._adam_args(lr_dev=self.opt.lr_dev))
+            return
         self._head_and_backward(emb_u, emb_i, self._target_buf)
         scale = 1.0
         if with_collective:

@@ -220,19 +220,37 @@ class SageTrainEngine(SageForwardEngine):
         return self.g_xs[layer][t]
 
     # ---- backward -----------------------------------------------------------------
-    def backward_head(self, head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss):
+    def can_update_in_backward(self, grads_flat, head_grads):
+        """True when ``backward_head`` can apply the optimizer step inside its reduction: the one-kernel
+        backward pass runs on the model's own weights, and the gradients it writes (the aggregators' and
+        ``head_grads``) are views of ``grads_flat`` that cover all of it."""
+        m = self.model
+        relu0 = all(m._aggs[0][t].activation == 'relu' for t in _TYPES)
+        if not (self.fused_backward and self._tail_kernel and (self.h1_mask is not None or not relu0)):
+            return False
+        if self._padded_model is not None:
+            return False
+        gs = [g for layer in (0, 1) for t in _TYPES for g in self._grads_of(m._aggs[layer][t]) if g is not None] + list(head_grads)
+        lo, hi = grads_flat.data_ptr(), grads_flat.data_ptr() + grads_flat.numel() * 4
+        return (all(lo <= g.data_ptr() and g.data_ptr() + g.numel() * 4 <= hi for g in gs)
+                and sum(g.numel() for g in gs) == grads_flat.numel())
+
+    def backward_head(self, head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss, adam=None):
         """The link head (concat -> Dense(1, sigmoid), mean squared error against ``targets``) and the
         whole backward pass from the embeddings ``forward_train`` left in the engine: the head is
         evaluated inside the kernel that starts the backward pass, its parameter gradients and the loss
-        are summed beside the weight gradients.  Only when ``tail_kernel``."""
+        are summed beside the weight gradients.  Only when ``tail_kernel``.  ``adam`` (see
+        ``kernels.Sage2BackwardAll.run``; only when ``can_update_in_backward``): the optimizer step in the
+        same reduction."""
         if not self.tail_kernel:
             raise kernels._lib.GsageError("backward_head needs the two-hop one-kernel route")
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
-        return self._backward_walks(None, None, main, head=(head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss))
+        return self._backward_walks(None, None, main, head=(head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss),
+                                    adam=adam)
 
-    def _backward_walks(self, g_user, g_item, main, head=None):
+    def _backward_walks(self, g_user, g_item, main, head=None, adam=None):
         """Two hops on the one-kernel forward's tables: one launch takes the embedding
         gradients through the l2 normalisation, the layer-1 input gradients and the
         neighbor-mean broadcast for both node types; after it only weight gradients
@@ -267,12 +285,15 @@ class SageTrainEngine(SageForwardEngine):
                                                 input_scale=1.0 / (1.0 - self.dropout) if self.dropout else 1.0)
                 self._bwd_all = (key, call)
             if head is not None:
-                self._bwd_all[1].run(targets=head[2])
+                self._bwd_all[1].run(targets=head[2], adam=adam)
             else:
                 self._bwd_all[1].run(g_emb={'user': g_user.contiguous(), 'item': g_item.contiguous()})
             if self._padded_model is not None:
                 self._padded_model.scatter_grads()
             return
+        if adam is not None:
+            raise kernels._lib.GsageError("the optimizer step inside the backward pass needs its one-kernel form "
+                                          "(can_update_in_backward)")
         if self._side2 is None:
             self._side2 = torch.cuda.Stream()
         l0_mask = None if self.h1_mask is None else {'h1': self.h[0], 'h1_mask': self.h1_mask}

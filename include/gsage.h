@@ -640,6 +640,22 @@ int gs_link_head_reduce(const void *slab, int n_rows, int E, int64_t B, float *g
  * bitwise reproducible.  Shapes: gs_sage2_backward_all_supported() != 0 (both feature widths F = 32 or 64,
  * H1 = H2 = 32: a wavefront keeps every sum in registers), else GS_ELIMIT.
  */
+/*
+ * adam (nullable argument of gs_sage2_backward_all): the optimizer step of gs_adam_step, applied by the
+ * reduction to every gradient element it has just written -- one launch less when no collective stands
+ * between the gradients and the update (train_movielens.py:183, Adam).  Every g_* pointer of the call must
+ * lie inside grads[0 .. n); params, m, v are flat buffers indexed like grads; the rate comes from
+ * lr_t_device[0] when that is not NULL (a captured graph), else from lr_t; elements of the flat buffers
+ * that no g_* pointer covers are left alone.
+ */
+typedef struct gs_adam_update {
+    const float *grads;
+    float *params, *m, *v;
+    int64_t n;
+    const float *lr_t_device;
+    float lr_t, beta_1, beta_2, epsilon, grad_scale;
+} gs_adam_update;
+
 typedef struct gs_sage2_bwd_all {
     const float *z[2], *emb[2], *g_emb[2];
     const float *targets, *head_kernel, *head_bias;
@@ -659,7 +675,8 @@ typedef struct gs_sage2_bwd_all {
 int gs_sage2_backward_all_supported(int Fu, int Fi, int H1, int H2);
 size_t gs_sage2_backward_all_workspace(int64_t n_pairs, int F, int H1, int H2);
 int gs_sage2_backward_all(const gs_sage2_bwd_all *p, int64_t n_pairs, int n0, int F, int H1, int H2,
-                          int normalize, int act, void *workspace, size_t workspace_bytes, void *stream);
+                          int normalize, int act, void *workspace, size_t workspace_bytes,
+                          const gs_adam_update *adam, void *stream);
 
 /*
  * Link head of the reference's training script: concat(user_emb, item_emb) ->

@@ -316,37 +316,46 @@ int main() {
     EXPECT(gs_sage2_backward_all_workspace(3, 32, 32, 32) == ((size_t)1 * (2 * (2 * 32 * 16 + 32) + 2 * (2 * 32 * 16 + 32) + 66) + 2 * 3 * 32) * 4);
     {
         gs_sage2_bwd_all p{};
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(nullptr, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 0, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 0, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
-        REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, 8, 25, 128, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
-        REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, 8, 25, 64, 32, 64, 1, GS_ACT_LINEAR, arena, ba, nullptr));
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, 77, arena, ba, nullptr));
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));   // null tables
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(nullptr, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 0, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 0, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
+        REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, 8, 25, 128, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
+        REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, 8, 25, 64, 32, 64, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, 77, arena, ba, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));   // null tables
         for (int t = 0; t < 2; ++t) {
             p.z[t] = p.w1_self[t] = p.w1_neigh[t] = p.h1[t] = p.x_mean1[t] = p.x_self[t] = p.x_mean[t] = f;
             p.g_emb[t] = f;
         }
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 4096, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba - 4, nullptr));
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, nullptr, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 4096, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba - 4, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, nullptr, ba, nullptr, nullptr));
         p.g_emb[1] = nullptr;
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
         p.g_emb[1] = f;
         p.targets = f;                                           // the head form: emb, head weights and outputs are needed
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
         p.emb[0] = p.emb[1] = f;
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
         p.targets = nullptr;
         p.self_ids[0] = i32;                                     // ids for one node type only
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
         p.self_ids[1] = i32;                                     // ids without the table's row count
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
         p.self_ids[0] = p.self_ids[1] = nullptr;
         p.h1_mask[1] = reinterpret_cast<const uint32_t *>(f);    // mask words for one node type only
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
         p.h1_mask[1] = nullptr;
+        {
+            float *gw = reinterpret_cast<float *>(arena + 3072);
+            for (int t = 0; t < 2; ++t) p.g_w0_self[t] = p.g_w0_neigh[t] = p.g_w1_self[t] = p.g_w1_neigh[t] = gw;
+            gs_adam_update ad{};
+            REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, &ad, nullptr));   // empty
+            ad.grads = f; ad.params = ad.m = ad.v = f; ad.n = 16;                                  // gradients outside grads[0 .. n)
+            REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, &ad, nullptr));
+            for (int t = 0; t < 2; ++t) p.g_w0_self[t] = p.g_w0_neigh[t] = p.g_w1_self[t] = p.g_w1_neigh[t] = nullptr;
+        }
         p.x_mean[0] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(f) + 4);   // not 16-byte aligned
-        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr));
+        REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
     }
 
     // ---- link head, optimizer, staging ----

@@ -618,6 +618,39 @@ def test_whole_backward_in_one_kernel_equals_the_separate_launches(cuda, b, ns, 
     assert grads[0][0] == grads[2][0] and torch.equal(grads[0][1], grads[2][1])
 
 
+@pytest.mark.parametrize('mode', ['device', 'graph'])
+def test_optimizer_step_inside_the_backward_reduction_equals_the_separate_launch(cuda, mode):
+    """Three steps with Adam applied by the reduction of the one-kernel backward pass and three with the
+    update as a launch of its own: the same weights and the same moments."""
+    from graphsage_amd.train import LinkHead
+    g, links, targets = _toy(5, fu=64, fi=64)
+    b, ns, sizes = 40, [6, 3], [32, 32]
+    out = []
+    for fuse in (True, False):
+        gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+        model = ga.GraphSAGE(sizes, gen, seed=11)
+        model.build()
+        tr = Trainer(model, head=LinkHead(sizes[-1], cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
+        assert tr._update_in_backward()
+        tr.fuse_update = fuse
+        step = tr.step_device if mode == 'device' else tr.step_graph
+        losses = []
+        for k in range(3):
+            lk = np.asarray(links[k * b:(k + 1) * b])
+            seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+            loss, _ = step(seeds, torch.from_numpy(targets[k * b:(k + 1) * b]).to(cuda),
+                           torch.arange(2 * b, dtype=torch.int64, device=cuda) + 2 * b * k, rng_seed=9)
+            losses.append(float(loss))
+        out.append((losses, tr.opt.p_flat.clone(), tr.opt.m.clone(), tr.opt.v.clone(), tr.opt.t))
+    (l0, p0, m0, v0, t0), (l1, p1, m1, v1, t1) = out
+    assert t0 == t1 == 3
+    assert np.allclose(l0, l1, rtol=1e-6, atol=0)
+    assert float((p0 - p1).abs().max()) < 1e-6
+    assert float((m0 - m1).abs().max()) <= 1e-6 * float(m1.abs().max())
+    assert float((v0 - v1).abs().max()) <= 1e-6 * float(v1.abs().max())
+    assert float((p0 - out[0][1]).abs().max()) == 0 and l0[2] < l0[0] + 1e-3
+
+
 def test_stage_batch_copies_inputs_and_rate_in_one_launch(cuda):
     from graphsage_amd import kernels
     gen = torch.Generator(device=cuda).manual_seed(1)
