@@ -402,7 +402,7 @@ void sage2_bwd_all_kernel(const AllArgs a) {
     }
 }
 
-// Adds the slab rows in block order: element e is summed by eight threads that take rows b = j, j + 8, ...
+// Adds the slab rows in block order: element e is summed by sixteen threads that take rows b = j, j + 16, ...
 // each in increasing order; their partial sums are then added in index order.  A table of segments says
 // where each stretch of the slab row goes.
 struct Segment {
@@ -425,27 +425,29 @@ struct ReduceArgs {
     AdamArgs adam;
 };
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(512)
 void sage2_bwd_reduce_kernel(const ReduceArgs a) {
-    __shared__ float part[256];
+    __shared__ float part[512];
     const int e = blockIdx.x * 32 + (threadIdx.x & 31), j = threadIdx.x >> 5;
     float s = 0.f;
     if (e < a.row_floats) {
         const float *p = a.slab + e;
         int b = j;
-        for (; b + 24 < a.n_rows; b += 32) {                      // four reads in flight
-            const float x0 = p[(size_t)b * a.row_floats], x1 = p[(size_t)(b + 8) * a.row_floats];
-            const float x2 = p[(size_t)(b + 16) * a.row_floats], x3 = p[(size_t)(b + 24) * a.row_floats];
-            s += x0; s += x1; s += x2; s += x3;
+        for (; b + 112 < a.n_rows; b += 128) {                    // eight reads in flight
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = p[(size_t)(b + 16 * i) * a.row_floats];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += x[i];
         }
-        for (; b < a.n_rows; b += 8) s += p[(size_t)b * a.row_floats];
+        for (; b < a.n_rows; b += 16) s += p[(size_t)b * a.row_floats];
     }
     part[threadIdx.x] = s;
     __syncthreads();
     if (j == 0 && e < a.row_floats) {
         s = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) s += part[g * 32 + threadIdx.x];
+        for (int g = 0; g < 16; ++g) s += part[g * 32 + threadIdx.x];
         for (int i = 0; i < a.n_seg; ++i)
             if (e >= a.seg[i].begin && e < a.seg[i].end) {
                 if (a.seg[i].dst) {
@@ -590,6 +592,6 @@ extern "C" int gs_sage2_backward_all(const gs_sage2_bwd_all *p, int64_t n_pairs,
     if (int rc = gs::check_launch(who)) return rc;
 
     ra.n_seg = n; ra.n_rows = (int)blocks; ra.row_floats = slab_floats(F, H2); ra.slab = a.slab;
-    hipLaunchKernelGGL(sage2_bwd_reduce_kernel, dim3((unsigned)((ra.row_floats + 31) / 32)), dim3(256), 0, s, ra);
+    hipLaunchKernelGGL(sage2_bwd_reduce_kernel, dim3((unsigned)((ra.row_floats + 31) / 32)), dim3(512), 0, s, ra);
     return gs::check_launch("gs_sage2_backward_all (reduce)");
 }
