@@ -38,6 +38,15 @@ struct Draws {
     int32_t *err;
 };
 
+// Wide layers: which tiles a block takes.  Blocks b0 .. (the next class's b0) - 1 form a class of w blocks; the class
+// takes, of segment s, the w * count[s] tiles from start[s] on (tiles numbered inside the segment), dealt round-robin:
+// block b takes start[s] + (b - b0) + i * w, i < count[s].
+constexpr int kMaxTileClasses = 12;
+struct TileClass {
+    int b0;
+    int start[kMaxSegs], count[kMaxSegs];
+};
+
 struct FusedArgs {
     const float *feat_self;  long long n_rows_self;  long long off_self;
     const float *feat_neigh; long long n_rows_neigh; long long off_neigh;
@@ -49,6 +58,11 @@ struct FusedArgs {
     int act, normalize, max_child;
     Draws draws;               // used when some segment has hop >= 0
     void *split_ws;            // wide layers: workspace of the bf16-piece form of the product (NULL: the fp32 form)
+};
+
+struct TilePlan {              // wide layers: the blocks' shares (a kernel argument of its own, set by sage_wide_fwd)
+    TileClass cls[kMaxTileClasses];
+    int n_cls;
 };
 
 // Wide layers (wide.hip).  `a.seg[].tile0` / `a.n_tiles` are recomputed for 128-head tiles.

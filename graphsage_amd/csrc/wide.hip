@@ -57,6 +57,9 @@
 // finished piece there.
 #include "fused_args.h"
 
+#include <algorithm>
+#include <vector>
+
 namespace {
 
 // Diagnostic build (-DGS_WIDE_STAMP, tools/build_variant.sh): shader-clock stamps around the waits and phases of
@@ -81,6 +84,7 @@ __device__ __forceinline__ gf32x4 *global_ptr(unsigned long long p) { return (gf
 using gs::FusedArgs;
 using gs::Seg;
 using gs::kMaxSegs;
+using gs::TilePlan;
 
 constexpr int WM = 128, WN = 128, WK = 32;
 constexpr int W_TILE = WM * WK;                 // floats of one operand slice (A or B): 16 KB
@@ -147,7 +151,11 @@ struct Cursor {
 struct Shape {
     int Fs, Fn, HH;
     int ns, nn, nct;    // k slices per half, column tiles per half
-    int stride;         // tiles between two tiles of one block
+    // (a pointer that says "LDS" in its type: read through a generic pointer these words would be flat loads, which
+    // count as reads of global memory and would make every wait behind them a wait for all row loads in flight)
+    const __attribute__((address_space(3))) int *plan;
+                        // LDS [kMaxSegs][2]: of segment s this block takes the tiles first, first + step, ... below `end` (numbered
+                        // inside the segment); [2 * kMaxSegs]: step, the number of blocks of its class
 };
 
 // (uniform values are kept to 32 bits where they are compared: the scalar unit has no ordered 64-bit
@@ -158,6 +166,25 @@ __device__ __forceinline__ int find_seg(const FusedArgs &a, int tile) {
     for (int s = 1; s < kMaxSegs; ++s)
         if (s < a.n_segs && tile >= (int)a.seg[s].tile0) si = s;
     return __builtin_amdgcn_readfirstlane(si);       // a scalar: a.seg[si] is then read with scalar loads
+}
+
+// A block's tiles: segment after segment, every step-th tile of the part of the segment its class of blocks
+// takes (the host sizes the parts so that the blocks' gather work is level: a tile of a segment with 25 children
+// per head costs four of one with 5).  Blocks of a class work on neighboring tiles at any time, as round-robin
+// dealing would have them: runs of consecutive tiles per block put all blocks on the same memory channels at once.
+__device__ __forceinline__ int plan_first(const Shape &sh, const FusedArgs &a, int from_seg) {
+    int si = kMaxSegs;                               // the first segment from from_seg on of which the block has a tile left
+#pragma unroll
+    for (int s = kMaxSegs - 1; s >= 0; --s)
+        if (s >= from_seg && s < a.n_segs && sh.plan[2 * s] < sh.plan[2 * s + 1]) si = s;
+    si = __builtin_amdgcn_readfirstlane(si);         // (a scalar, as in find_seg: a.seg[si] is then read with scalar loads)
+    if (si == kMaxSegs) return (int)a.n_tiles;       // no tile left
+    return (int)a.seg[si].tile0 + __builtin_amdgcn_readfirstlane(sh.plan[2 * si]);
+}
+__device__ __forceinline__ int plan_next(int tile, const Shape &sh, const FusedArgs &a) {
+    const int s = find_seg(a, tile);
+    const int next = tile + __builtin_amdgcn_readfirstlane(sh.plan[2 * kMaxSegs]);
+    return next < (int)a.seg[s].tile0 + __builtin_amdgcn_readfirstlane(sh.plan[2 * s + 1]) ? next : plan_first(sh, a, s + 1);
 }
 
 __device__ __forceinline__ void enter_tile(Cursor &c, const FusedArgs &a) {
@@ -176,7 +203,7 @@ __device__ __forceinline__ void advance(Cursor &c, const Shape &sh, const FusedA
     c.side = 0;
     if (++c.ct < sh.nct) return;
     c.ct = 0;
-    c.tile += sh.stride;
+    c.tile = plan_next(c.tile, sh, a);
     ++c.local;
     enter_tile(c, a);
 }
@@ -545,7 +572,7 @@ struct Producer {
 // ---- kernel ---------------------------------------------------------------------
 template <int NPT, int CH, bool BIG, bool SPLIT>
 __global__ __launch_bounds__(kConsumerThreads + NPT)
-void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int HH, const int kStages) {
+void sage_wide_kernel(const FusedArgs a, const TilePlan tp, const int Fs, const int Fn, const int HH, const int kStages) {
     extern __shared__ __align__(16) float w_smem[];
     float *st = w_smem;                                            // kStages operand slices
     // after them: the four epilogue patches [16][EP_LD] (fp32 form) or the two buffers of the weight pieces (SPLIT)
@@ -554,27 +581,50 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     uint32_t *empty = full + kMaxStages;                           // [kMaxStages] consumer reads issued, ever
     uint32_t *bfull = empty + kMaxStages;                          // SPLIT [2]: consumer waves whose part of a weight buffer has landed, ever
     uint32_t *bempty = bfull + 2;                                  // SPLIT [2]: consumer waves that have read a weight buffer, ever
-    uint32_t *hrow = bempty + 2;                                   // [8 waves][2][16] keys of the own rows of a tile
+    int *plan = reinterpret_cast<int *>(bempty + 2);               // [kMaxSegs][2] + 4: this block's tiles in every segment (Shape::plan)
+    uint32_t *hrow = bempty + 2 + 2 * kMaxSegs + 4;                // [8 waves][2][16] keys of the own rows of a tile
     uint32_t *crow = hrow + kProducerWaves * 2 * kWaveRows;        // [8 waves][2][16 * max_child] child rows of a tile
 
     const int tid = threadIdx.x;
     Shape sh;
     sh.Fs = Fs; sh.Fn = Fn; sh.HH = HH;
     sh.ns = Fs / WK; sh.nn = Fn / WK; sh.nct = HH / WN;
-    sh.stride = (int)gridDim.x;
+    sh.plan = (const __attribute__((address_space(3))) int *)plan;
     const int n_tiles = (int)a.n_tiles;
-    const int my_tiles = (n_tiles - (int)blockIdx.x + sh.stride - 1) / sh.stride;
-    const int T = my_tiles * sh.nct * (sh.ns + sh.nn);              // k slices of this block
     const int H = 2 * HH;
     bool stalled = false;                                          // some wait of this wave gave up
 
     if (tid < 2 * kMaxStages + 4) full[tid] = 0u;
+    if (tid == 0) {                                                // this block's share, from its class (scalar reads of the arguments)
+        int ci = 0;
+        for (int i = 1; i < tp.n_cls; ++i)
+            if ((int)blockIdx.x >= tp.cls[i].b0) ci = i;
+        ci = __builtin_amdgcn_readfirstlane(ci);
+        const int b0 = tp.cls[ci].b0;
+        const int width = (ci + 1 < tp.n_cls ? tp.cls[ci + 1].b0 : (int)gridDim.x) - b0;
+#pragma unroll
+        for (int s = 0; s < kMaxSegs; ++s) {
+            const int cnt = s < a.n_segs ? tp.cls[ci].count[s] : 0;
+            const int first = s < a.n_segs ? tp.cls[ci].start[s] + ((int)blockIdx.x - b0) : 0;
+            plan[2 * s] = first;
+            plan[2 * s + 1] = first + cnt * width;                 // (past the last one)
+        }
+        plan[2 * kMaxSegs] = width;
+    }
     block_sync();                                                  // the only block barrier
+    int my_tiles = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxSegs; ++s)
+        my_tiles += (__builtin_amdgcn_readfirstlane(plan[2 * s + 1]) - __builtin_amdgcn_readfirstlane(plan[2 * s])) /
+                    __builtin_amdgcn_readfirstlane(plan[2 * kMaxSegs]);
+    const int T = my_tiles * sh.nct * (sh.ns + sh.nn);              // k slices of this block
+    const int first_tile = plan_first(sh, a, 0);
+    if (my_tiles == 0) return;
 
     if (tid >= kConsumerThreads) {
         Producer<NPT, CH, BIG, SPLIT> pr(a, sh, st, hrow, crow, tid - kConsumerThreads);
         typename Producer<NPT, CH, BIG, SPLIT>::Slice s0, s1;      // slices of even / odd index
-        Cursor cl{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0};      // next slice to load
+        Cursor cl{first_tile, 0, 0, 0, 0, 1, 1.f, 0, 0};      // next slice to load
         enter_tile(cl, a);
         Cursor cc = cl;                                            // slice that goes to LDS next
         int gl = 0;                                                // index of cl; past the last slice it stays there
@@ -595,6 +645,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
         // slice g+2.  At the first slice of a tile the ids of the block's next tile are requested, ahead
         // of the row loads of that slice; one slice later they have arrived and go to the id patch.
         bool ids_wait = false;                                     // id loads in flight, issued in the previous slice
+        int next_tile = n_tiles;                                   // the tile after cc's, looked up at a tile's first slice
 #define WD_PRODUCE(S_, O_)                                                                          \
             STAMP(tf0) pr.finish(S_, stage, O_.cnt, ids_wait);                                      \
             flag_add(full + stage);                                                                 \
@@ -606,8 +657,9 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
             STAMP_ADD(t_beg[bside], tb0)
 #define WD_TICK(S_, O_)                                                                             \
         {                                                                                           \
-            const int next_tile = cc.tile + sh.stride;                                              \
-            const bool stage_ids = cc.ct == 0 && cc.side == 0 && cc.ks == 0 && next_tile < n_tiles; \
+            const bool tile_begins = cc.ct == 0 && cc.side == 0 && cc.ks == 0;                      \
+            if (tile_begins) next_tile = plan_next(cc.tile, sh, a);                                 \
+            const bool stage_ids = tile_begins && next_tile < n_tiles;                              \
             STAMP(t0s)                                                                              \
             if (use && !flag_wait(empty + stage, use * kConsumerWaves, flag_peek(empty + stage))) stalled = true; \
             STAMP_ADD(t_empty[cc.side], t0s)                                                        \
@@ -772,7 +824,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
             }
         };
 
-        Cursor c{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0};
+        Cursor c{first_tile, 0, 0, 0, 0, 1, 1.f, 0, 0};
         Cursor cn = c;                                              // the slice after c (the last one stays put)
         issue_b(c, 0);
         if (T > 1) advance(cn, sh, a);
@@ -877,7 +929,7 @@ void sage_wide_kernel(const FusedArgs a, const int Fs, const int Fn, const int H
     // one k step of a half, then the reload of its weight register for the next slice
 #define WD_STEP(S_, st_) { WD_MFMA_STEP(S_, st_) __builtin_amdgcn_sched_barrier(0); WD_LOAD_B(S_, st_) __builtin_amdgcn_sched_barrier(0); }
 
-    Cursor c{(int)blockIdx.x, 0, 0, 0, 0, 1, 1.f, 0, 0};
+    Cursor c{first_tile, 0, 0, 0, 0, 1, 1.f, 0, 0};
     Cursor cn = c;                                                  // the slice after c (the last one stays put)
     WD_B_BASE(c, 0) WD_LOAD_B(X, 0) WD_LOAD_B(X, 1) WD_LOAD_B(X, 2) WD_LOAD_B(X, 3)
     WD_B_BASE(c, 1) WD_LOAD_B(Y, 0) WD_LOAD_B(Y, 1) WD_LOAD_B(Y, 2) WD_LOAD_B(Y, 3)
@@ -950,7 +1002,7 @@ constexpr int kProducerThreads = 512, kChunk = 5;
 
 inline size_t wide_lds_bytes(int max_child, bool split, int stages) {
     return (size_t)(stages * (split ? W_TILE_S : W_TILE) + (split ? 2 * W_TILE_S : 4 * 16 * EP_LD)) * sizeof(float) +
-           (size_t)(2 * kMaxStages + 4 + 2 * WM + 2 * WM * max_child) * sizeof(int32_t);
+           (size_t)(2 * kMaxStages + 4 + 2 * kMaxSegs + 4 + 2 * WM + 2 * WM * max_child) * sizeof(int32_t);
 }
 constexpr size_t kWideLdsMax = 160 * 1024;
 // fp32 form: four stages.  SPLIT: as many as fit beside the two weight buffers and the id patches (the stages are
@@ -990,6 +1042,78 @@ size_t gs::sage_wide_workspace_bytes(int Fs, int Fn, int H) {
     return (size_t)3 * (H / 2) * ((size_t)Fs + Fn) * sizeof(uint16_t);
 }
 
+namespace {
+using namespace gs;
+
+// The blocks' shares of the tiles.  A tile's time grows with the children it gathers per head -- measured on 256-wide
+// rows: 490 / 680 / 1179 us for 2048 tiles of 5 / 10 / 25 children, i.e. proportional to 9 + children -- so tiles
+// dealt round-robin leave the blocks that drew the few expensive tiles (the seeds' segment: 25 children) behind
+// the others at the end of the launch.  Here every segment, the most expensive
+// first, is handed out in rounds to the blocks that have the least work so far; blocks with equal shares form a
+// class (at most one new class per segment), and a class's part of a segment is dealt round-robin inside the class.
+constexpr double kTileFixedCost = 9.0;      // a tile's time in units of one child per head (see above)
+
+int plan_tiles(const FusedArgs &a, int blocks, TilePlan &tp) {
+    struct Class { int b0, b1; double load; long long cnt[kMaxSegs]; };
+    std::vector<Class> cls(1);
+    cls[0] = Class{0, blocks, 0.0, {}};
+    int order[kMaxSegs];
+    for (int s = 0; s < a.n_segs; ++s) order[s] = s;
+    std::stable_sort(order, order + a.n_segs, [&](int x, int y) { return a.seg[x].n_child > a.seg[y].n_child; });
+    for (int oi = 0; oi < a.n_segs; ++oi) {
+        const int s = order[oi];
+        const double cost = kTileFixedCost + a.seg[s].n_child;
+        long long left = (a.seg[s].n_heads + WM - 1) / WM;
+        while (left > 0) {
+            size_t m = 0;
+            double lo2 = 1e300, hi = -1e300;
+            for (size_t i = 0; i < cls.size(); ++i) {
+                if (cls[i].load < cls[m].load) m = i;
+                if (cls[i].load > hi) hi = cls[i].load;
+            }
+            for (size_t i = 0; i < cls.size(); ++i)
+                if (i != m && cls[i].load < lo2) lo2 = cls[i].load;
+            if (hi - cls[m].load < cost && left >= blocks) {        // level: whole rounds for everybody
+                const long long q = left / blocks;
+                for (auto &c : cls) { c.cnt[s] += q; c.load += q * cost; }
+                left -= q * blocks;
+                continue;
+            }
+            const long long width = cls[m].b1 - cls[m].b0;
+            long long k = 1;                                        // rounds until the class catches up with the next one
+            if (lo2 < 1e299 && lo2 > cls[m].load) k = std::max(1ll, (long long)((lo2 - cls[m].load) / cost));
+            k = std::min(k, left / width);
+            if (k >= 1) {
+                cls[m].cnt[s] += k;
+                cls[m].load += k * cost;
+                left -= k * width;
+            } else {                                                // fewer tiles than blocks in the class: its first blocks take one more
+                Class rest = cls[m];
+                rest.b0 = cls[m].b0 + (int)left;
+                cls[m].b1 = rest.b0;
+                cls[m].cnt[s] += 1;
+                cls[m].load += cost;
+                cls.insert(cls.begin() + m + 1, rest);
+                left = 0;
+            }
+        }
+    }
+    if ((int)cls.size() > kMaxTileClasses) return gs::fail(GS_ELIMIT, "gs_sage_fused_fwd: %zu classes of blocks", cls.size());
+    tp.n_cls = (int)cls.size();
+    long long run[kMaxSegs] = {};
+    for (int i = 0; i < tp.n_cls; ++i) {
+        tp.cls[i].b0 = cls[i].b0;
+        for (int s = 0; s < kMaxSegs; ++s) {
+            tp.cls[i].start[s] = (int)run[s];
+            tp.cls[i].count[s] = s < a.n_segs ? (int)cls[i].cnt[s] : 0;
+            if (s < a.n_segs) run[s] += (long long)(cls[i].b1 - cls[i].b0) * cls[i].cnt[s];
+        }
+    }
+    return GS_OK;
+}
+
+}  // namespace
+
 int gs::sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream) {
     long long tiles = 0, rows = 0;
     for (int s = 0; s < a.n_segs; ++s) {
@@ -1017,7 +1141,9 @@ int gs::sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
         return n;
     }();
-    const long long blocks = tiles < n_cu ? tiles : n_cu;          // one block per CU (LDS), tiles dealt round-robin
+    const long long blocks = tiles < n_cu ? tiles : n_cu;          // one block per CU (LDS)
+    TilePlan tp{};
+    if (int rc = plan_tiles(a, (int)blocks, tp)) return rc;
     const dim3 grid((unsigned)blocks), block(kConsumerThreads + kProducerThreads);
     const int stages = wide_stages(a.max_child, split);
     const size_t lds = wide_lds_bytes(a.max_child, split, stages);
@@ -1030,13 +1156,13 @@ int gs::sage_wide_fwd(FusedArgs a, int Fs, int Fn, int H, hipStream_t stream) {
         hipLaunchKernelGGL(wide_split_weights_kernel, dim3((unsigned)(((long long)Fn * hh + 255) / 256)), dim3(256), 0, stream, a.W_neigh, Fn, hh,
                            ws + (size_t)3 * hh * Fs);
         if (big)
-            gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, true, true>, grid, block, lds, stream, a, Fs, Fn, hh, stages);
+            gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, true, true>, grid, block, lds, stream, a, tp, Fs, Fn, hh, stages);
         else
-            gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, false, true>, grid, block, lds, stream, a, Fs, Fn, hh, stages);
+            gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, false, true>, grid, block, lds, stream, a, tp, Fs, Fn, hh, stages);
     } else if (big)
-        gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, true, false>, grid, block, lds, stream, a, Fs, Fn, H / 2, stages);
+        gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, true, false>, grid, block, lds, stream, a, tp, Fs, Fn, H / 2, stages);
     else
-        gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, false, false>, grid, block, lds, stream, a, Fs, Fn, H / 2, stages);
+        gs::launch_timed(sage_wide_kernel<kProducerThreads, kChunk, false, false>, grid, block, lds, stream, a, tp, Fs, Fn, H / 2, stages);
     int rc = gs::check_launch("gs_sage_fused_fwd");
     if (rc != GS_OK || !a.normalize) return rc;
     long long nb = (rows + 3) / 4;
