@@ -16,6 +16,11 @@
 // arrive, and what that needs was read one walk ahead.  A block's eight waves add their sums in a
 // fixed tree through LDS and leave one slab row; sage2_bwd_reduce_kernel adds the rows in block order, so
 // the result does not depend on scheduling.
+//
+// Builds for timing experiments (tools/build_variant.sh, tools/time_bwd_all.py; results are wrong on purpose):
+// -DGS_BA_NO_ROWS every row read from one cached line, -DGS_BA_NO_WALK without the per-walk arithmetic,
+// -DGS_BA_NO_MFMA the products on the vector ALU's first element only, -DGS_BA_NO_TAIL without the sum over
+// waves, -DGS_BA_NO_LOOP the prologue alone.
 #include "gs_common.h"
 
 namespace {
