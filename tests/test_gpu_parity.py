@@ -627,6 +627,41 @@ def test_wide_fused_layer_many_tiles_equals_separate_kernels(cuda, fs, fn, h, n_
         start += nh
 
 
+@pytest.mark.parametrize('pieces', [True, False])
+@pytest.mark.parametrize('shape', [
+    [(4096, 25), (102400 // 4, 10), (1024000 // 16, 5)],                          # the three-hop mix: few expensive tiles first
+    [(40 * 128, 1), (3, 32), (700 * 128 + 1, 2), (128, 17), (129, 9), (5000, 4), (1, 1), (260 * 128, 3)],   # eight segments
+    [(100, 7), (90, 3)],                                                         # fewer tiles than blocks
+    [(256 * 128 * 3, 2)],                                                        # one segment, whole rounds
+])
+def test_wide_layer_every_tile_is_taken_once_whatever_the_mix_of_segments(cuda, shape, pieces):
+    """The blocks of the wide kernel share the tiles by estimated work (expensive segments first, classes of
+    blocks with equal shares): every head of every segment must come out, and equal gather + gather-mean +
+    projection, for segment mixes that give one class, several classes, empty shares and fewer tiles than blocks."""
+    fs = fn = 64
+    h = 256
+    rng = np.random.default_rng(len(shape) * 1000 + shape[0][0])
+    gen = torch.Generator().manual_seed(len(shape))
+    n_self, n_neigh = 4000, 3000
+    t_self = torch.from_numpy(rng.standard_normal((n_self, fs)).astype(np.float32)).to(cuda)
+    t_neigh = torch.from_numpy(rng.standard_normal((n_neigh, fn)).astype(np.float32)).to(cuda)
+    f32 = lambda t: t.float().to(cuda).contiguous()
+    ws, wn = f32(omodel.glorot_uniform(fs, h // 2, gen, torch.float64)), f32(omodel.glorot_uniform(fn, h // 2, gen, torch.float64))
+    bias = f32(torch.randn(h, generator=gen, dtype=torch.float64) * 0.1)
+    segs, want = [], []
+    for n_heads, nc in shape:
+        heads = torch.from_numpy(rng.integers(0, n_self, n_heads).astype(np.int32)).to(cuda)
+        kids = torch.from_numpy(rng.integers(0, n_neigh, n_heads * nc).astype(np.int32)).to(cuda)
+        segs.append({'head_ids': heads, 'child_ids': kids, 'n_heads': n_heads, 'n_child': nc})
+        want.append(kernels.sage_project(kernels.gather_rows(t_self, heads, 0), kernels.gather_mean(t_neigh, kids, n_heads, nc, 0),
+                                         ws, wn, bias, 'relu'))
+    want = torch.cat(want)
+    out = torch.full_like(want, float('nan'))                # a tile nobody takes stays NaN
+    got = kernels.sage_fused(t_self, 0, t_neigh, 0, segs, ws, wn, bias, 'relu', out=out, exact_pieces=pieces)
+    assert not bool(torch.isnan(got).any())
+    close(got, want, scale=float(want.abs().max()))
+
+
 def test_wide_kernel_wait_counts(cuda, tmp_path):
     """The wide kernel's producers wait for their row loads by count (``s_waitcnt vmcnt(N)`` with N the number
     of loads issued after the ones waited for).  A wrong count reads registers before their data arrives and
