@@ -20,8 +20,9 @@ node type instead of the two-launch route;
 BENCH_DRAW_IN_LAYER=1 lets the layer-0 kernel of the layered routes draw the deepest hop
 itself (the sampler kernel then stops one hop short);
 BENCH_NO_PIPELINE=1 skips the secondary measurement with two batches in flight;
-BENCH_EAGER_TRAIN=1 launches the training step kernel by kernel instead of
-replaying a captured HIP graph; BENCH_WATCHDOG_S bounds the whole run.
+BENCH_EAGER_TRAIN=1 launches the training step kernel by kernel, BENCH_GRAPH_TRAIN=1
+replays it from a captured HIP graph (default: the graph, except for the three-launch
+step of the one-kernel route on one GPU); BENCH_WATCHDOG_S bounds the whole run.
 """
 import argparse
 import gc
@@ -483,9 +484,12 @@ def main():
         def timed_training():
             tgt = (torch.arange(b, device=device) % 2).to(torch.float32)
 
-            # the step's launches are replayed from a captured HIP graph; with several GPUs the graph
-            # ends after backward, the RCCL all-reduce and the update follow it on the stream
-            mode = {'fn': tr.step_device if os.environ.get('BENCH_EAGER_TRAIN') else tr.step_graph}
+            # the step's launches are replayed from a captured HIP graph (with several GPUs the graph ends after
+            # backward, the RCCL all-reduce and the update follow it on the stream) -- unless the step is the
+            # three launches of the one-kernel route on one GPU, which go out one by one (Trainer.step_is_short);
+            # BENCH_EAGER_TRAIN=1 / BENCH_GRAPH_TRAIN=1 force either
+            eager = bool(os.environ.get('BENCH_EAGER_TRAIN')) or (tr.step_is_short() and not os.environ.get('BENCH_GRAPH_TRAIN'))
+            mode = {'fn': tr.step_device if eager else tr.step_graph, 'eager': eager}
 
             def tstep(i):
                 k = my_batches[i % len(my_batches)]
@@ -504,14 +508,14 @@ def main():
             try:
                 warm_up()
             except Exception:
-                if mode['fn'] is tr.step_device:
+                if mode['eager']:
                     raise
                 # a capture that does not go through (every rank fails at the same place, before any
                 # collective of the step): the same step launch by launch
                 import traceback
                 traceback.print_exc()
                 print('[r%d] graph replay unavailable, timing the eager step' % rank, file=sys.stderr, flush=True)
-                mode['fn'] = tr.step_device
+                mode['fn'], mode['eager'] = tr.step_device, True
                 warm_up()
             if world > 1:
                 dist.barrier()
@@ -531,7 +535,7 @@ def main():
             return {"value": args.train_steps * b * world / t_el, "unit": "seed edges/s",
                     "ms_per_step": t_el / args.train_steps * 1e3, "steps": args.train_steps,
                     "what": "sample + fwd + bwd + flat-bucket all-reduce (RCCL for N>1) + Adam, MSE on concat->Dense(1,sigmoid)"
-                            + ("" if mode['fn'] is tr.step_device else "; launches replayed from a captured HIP graph")}
+                            + ("; launched one by one" if mode['eager'] else "; launches replayed from a captured HIP graph")}
 
         if tr is not None:
             try:
