@@ -545,7 +545,17 @@ __global__ __launch_bounds__(kThreads, 2)
 void wgrad_big_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_chunk) {
     extern __shared__ __align__(16) float wb_smem[];
     const int tiles0 = (s0.K / 128) * (s0.N / 128);
-    const bool second = (int)blockIdx.y >= tiles0;
+    // Blocks are numbered so that the tiles of one chunk of rows -- which read the same rows of G and of the
+    // mask -- start together and on one XCD (consecutive blocks go to the eight XCDs in turn): groups of eight
+    // chunks, within a group tile by tile.  The second reader of a row then finds it in that XCD's L2.
+    const int n_tiles_all = tiles0 + (s1.K / 128) * (s1.N / 128);
+    const int64_t n_chunks = (M + rows_per_chunk - 1) / rows_per_chunk;
+    const int64_t group = (int64_t)blockIdx.x / (8 * n_tiles_all);
+    const int in_group = (int)((int64_t)blockIdx.x % (8 * n_tiles_all));
+    const int tile_all = in_group >> 3;
+    const int64_t chunk = group * 8 + (in_group & 7);
+    if (chunk >= n_chunks) return;                               // (the last group is padded to eight chunks)
+    const bool second = tile_all >= tiles0;
 #define GS_SEL(f) (second ? s1.f : s0.f)
     const float *__restrict__ X = GS_SEL(X);
     const float *__restrict__ G = GS_SEL(G);
@@ -554,9 +564,8 @@ void wgrad_big_kernel(WgradSide s0, WgradSide s1, int64_t M, int64_t rows_per_ch
     const int K = GS_SEL(K), N = GS_SEL(N), ldg = GS_SEL(ldg);
 #undef GS_SEL
     const int ncb = N / 128;
-    const int tile = (int)blockIdx.y - (second ? tiles0 : 0);
+    const int tile = tile_all - (second ? tiles0 : 0);
     const int kb0 = (tile / ncb) * 128, col0 = (tile % ncb) * 128;
-    const int64_t chunk = blockIdx.x;
     const int64_t m_begin = chunk * rows_per_chunk;
     const int64_t m_end = min(M, m_begin + rows_per_chunk);      // > m_begin: the grid has no empty chunks
     const int tid = threadIdx.x;
@@ -1004,7 +1013,10 @@ inline int check_project_shape(const char *who, int Fs, int Fn, int64_t M, int H
 // chunks of the M dimension for the weight-gradient partial sums
 inline void wgrad_chunks(int64_t M, int64_t *rows_per_chunk, int64_t *n_chunks) {
     int64_t rpc = 128;                   // small chunks: enough blocks to fill the chip at M ~ 1e5
-    while ((M + rpc - 1) / rpc > 1024) rpc *= 2;
+    // Large M: 512 chunks (rows per chunk a multiple of the kernels' 32-row slices), so that chunks x tiles is a
+    // whole number of rounds on 256 compute units with two blocks each -- with power-of-two chunk sizes the
+    // last round of a launch ran a third full (2208 blocks on 512 places at M = 1.13e6).
+    if ((M + rpc - 1) / rpc > 512) rpc = (((M + 511) / 512 + 31) / 32) * 32;
     *rows_per_chunk = rpc;
     *n_chunks = M > 0 ? (M + rpc - 1) / rpc : 0;
 }
@@ -1102,7 +1114,7 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
             a.X = x_self; a.G = g_out; a.mask = mask; a.slab = slab0; a.K = Fs; a.N = Hh; a.ldg = H;
             b.X = x_mean; b.G = g_out + Hh; b.mask = mask ? mask + Hh : nullptr; b.slab = slab1; b.K = Fn; b.N = Hh; b.ldg = H;
             const int by = (Fs / 128 + Fn / 128) * (Hh / 128);
-            hipLaunchKernelGGL(wgrad_big_kernel, dim3((unsigned)nc, (unsigned)by), dim3(kThreads), WB_LDS, s, a, b, M, rpc);
+            hipLaunchKernelGGL(wgrad_big_kernel, dim3((unsigned)(((nc + 7) / 8) * 8 * by)), dim3(kThreads), WB_LDS, s, a, b, M, rpc);
             if (int rc = gs::check_launch("gs_sage_project_bwd (wgrad)")) return rc;
             direct = true;                         // slabs written in the layout the reduction below expects
         } else if (M > 0 && aligned16(x_self) && aligned16(x_mean) && aligned16(g_out) && (!mask || aligned16(mask))) {
