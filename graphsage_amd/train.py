@@ -331,6 +331,7 @@ class Trainer:
                                                self.head.bias, self.head.kernel.grad, self.head.bias.grad,
                                                self.head.kernel.device)
         eng._wgrad_pairs = None
+        eng._wgrad_l0_pair = None
         eng._bwd_all = None
         return True
 

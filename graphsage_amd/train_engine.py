@@ -89,6 +89,15 @@ class SageTrainEngine(SageForwardEngine):
             words = self.batch * self.fanouts[0] * (m.dims[1]['user'] // 32)
             self.h1_mask = {t: torch.zeros(words, dtype=torch.int32, device=dev) for t in _TYPES}
         self._head_slab = None
+        # The layered routes (other depths) do the same for layer 0 where its weight-gradient kernel reads own rows
+        # by id: the node ids of all layer-0 heads are put together in row order once per step (a few small copies),
+        # the layer's forward kernel writes no copy of the own rows, and both node types' weight gradients are one launch.
+        self.row_ids = None
+        self._wgrad_l0_pair = None
+        if (not self.walk_train and f['user'] == f['item'] and self.fused_layers[0] and not self.wide_layers[0] and
+                all(m._aggs[0][t].activation == 'relu' for t in _TYPES) and
+                kernels.load().gs_sage_project_wgrad_by_id_supported(f['user'], f['item'], m.dims[1]['user'])):
+            self.row_ids = {t: torch.zeros(self.h[0][t].shape[0], dtype=torch.int32, device=dev) for t in _TYPES}
         # Dropout of the aggregator inputs (models.py:152,165) is drawn inside the one-kernel forward; what that
         # kernel saves are the inputs as they entered the layers, so the own rows are saved as rows (not ids) and
         # the masks carry "active and kept".
@@ -150,7 +159,7 @@ class SageTrainEngine(SageForwardEngine):
         segs = self._layer_segments(layer, t)
         if layer == 0:
             (f_self, o_self), (f_neigh, o_neigh) = self.tables[t], self.tables[other[t]]
-            save_self = self.x_self[t]
+            save_self = None if self.row_ids is not None else self.x_self[t]
         else:
             f_self, o_self, f_neigh, o_neigh = self.h[layer - 1][t], 0, self.h[layer - 1][other[t]], 0
             save_self = None                                   # the own rows are h[layer-1] itself
@@ -170,6 +179,11 @@ class SageTrainEngine(SageForwardEngine):
         if self.walk_train:
             return self._forward_walks_train(seeds, walk_ids, rng_seed, replay)
         self.sample(seeds, walk_ids, rng_seed, replay)
+        if self.row_ids is not None:                         # the layer-0 heads' node ids in row order, for the backward pass
+            for t in _TYPES:
+                for (_, h, side, r0, n) in self.segments[t]:
+                    if h <= self.n_hops - 1:
+                        self.row_ids[t][r0:r0 + n].copy_(self._slot_ids(seeds, h, side))
         for layer in range(self.n_hops):
             if layer > 0 and self.wide_first_layer_only:
                 # wide models: the later layers have few rows; their neighbor means are needed in memory for
@@ -404,6 +418,21 @@ class SageTrainEngine(SageForwardEngine):
         self._side.wait_stream(main)
         for layer in range(L - 1, -1, -1):
             g_prev = self.g_h[layer - 1] if layer > 0 else None
+            if layer == 0 and self.row_ids is not None and L > 1:
+                # own rows from the feature tables by id, both node types in one launch (after the two streams met)
+                main.wait_stream(self._side)
+                if self._wgrad_l0_pair is None or self._wgrad_l0_pair.epoch != kernels.storage_epoch():
+                    problems = []
+                    for t in _TYPES:
+                        agg = m._aggs[0][t]
+                        g_ws, g_wn, g_b = self._grads_of(agg)
+                        rows = self.h[0][t].shape[0]
+                        problems.append({'x_self': self.tables[t][0], 'self_ids': self.row_ids[t], 'self_off': self.tables[t][1],
+                                         'x_mean': self.x_mean[0][t][:rows], 'out': self.h[0][t], 'g_out': g_out[t],
+                                         'g_w_self': g_ws, 'g_w_neigh': g_wn, 'g_bias': g_b, 'workspace': self.ws[0][t]})
+                    self._wgrad_l0_pair = kernels.WgradPairCall(problems, 'relu')
+                self._wgrad_l0_pair.run()
+                break
             for t in _TYPES:
                 with torch.cuda.stream(streams[t]):
                     if layer == L - 1:
