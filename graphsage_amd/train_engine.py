@@ -181,9 +181,8 @@ class SageTrainEngine(SageForwardEngine):
         self.sample(seeds, walk_ids, rng_seed, replay)
         if self.row_ids is not None:                         # the layer-0 heads' node ids in row order, for the backward pass
             for t in _TYPES:
-                for (_, h, side, r0, n) in self.segments[t]:
-                    if h <= self.n_hops - 1:
-                        self.row_ids[t][r0:r0 + n].copy_(self._slot_ids(seeds, h, side))
+                parts = [(r0, self._slot_ids(seeds, h, side)) for (_, h, side, r0, n) in self.segments[t] if h <= self.n_hops - 1]
+                torch.cat([ids for _, ids in sorted(parts, key=lambda x: x[0])], out=self.row_ids[t])    # one launch per type
         for layer in range(self.n_hops):
             if layer > 0 and self.wide_first_layer_only:
                 # wide models: the later layers have few rows; their neighbor means are needed in memory for
