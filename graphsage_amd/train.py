@@ -197,6 +197,7 @@ class Trainer:
         self._send = None
         self._coll_stream = None
         self._n_graph_steps = 0
+        self._n_plan_steps = 0                               # steps taken through the static plan (launched directly or replayed)
         self.model = model.build()
         dev = self.model.parameters()[0].device
         emb_dim = self.model.dims[-1]['user']
@@ -258,6 +259,7 @@ class Trainer:
         from . import kernels
         eng = self.engine
         self._prepare_head_step()
+        self._n_plan_steps += 1
         # every gradient of the bucket is overwritten by this step's kernels: no zeroing pass
         emb_u, emb_i = eng.forward_train(seeds, walk_ids, rng_seed)
         if not self._ranks()[0] and self._update_in_backward():
@@ -269,11 +271,13 @@ class Trainer:
         return loss, pred.reshape(-1, 1)
 
     def step_is_short(self):
-        """True when a step on this process is the three launches of the one-kernel route (forward, backward,
-        reduction with the update inside): launched one by one they leave no gap the host could not fill,
-        while a replayed graph pays its launch (8 us between two replays on MI355X) and a staging kernel for
-        its inputs -- measured at the benchmark shape: 158 us per step launched directly, 166 us replayed."""
-        return self.engine is not None and not self._ranks()[0] and self._update_in_backward()
+        """True when a step on this process is the handful of launches of the two-hop one-kernel route (forward,
+        backward, reduction, at most an update and the copies of a padded model): launched one by one they leave
+        no gap the host could not fill, while a replayed graph pays its launch (8 us between two replays on
+        MI355X) and a staging kernel for its inputs.  Measured, direct against replayed: 158 / 166 us at the
+        benchmark shape, 88 / 96 us at the MovieLens shape, 232 / 233 us with 64 hidden units; the layered routes
+        (dozens of launches on two streams) are faster replayed (three hops: 1.46 against 1.49 ms)."""
+        return self.engine is not None and not self._ranks()[0] and bool(getattr(self.engine, 'walk_train', False))
 
     def step_auto(self, seeds, targets, walk_ids, rng_seed=0):
         """``step_device`` where the step is short (``step_is_short``), ``step_graph`` otherwise."""
@@ -468,6 +472,7 @@ class Trainer:
             # launch that applies 1 / world to the gradients as it reads them
             self.opt.step(grad_scale=self.bucket.all_reduce_sum(self.group))
         self._n_graph_steps += 1
+        self._n_plan_steps += 1
         return self._head_step.loss, self._head_step.pred.reshape(-1, 1)
 
     # -- Keras-style loops over a LinkSequence ------------------------------------------

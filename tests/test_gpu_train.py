@@ -84,8 +84,8 @@ def test_short_run_learns(cuda, rate):
     seq = gen.flow(links, targets=targets, shuffle=True, seed=1)
     losses = []
     if rate:
-        losses = tr.fit(seq, epochs=15, verbose=0)['loss']       # full batches: replayed plan steps with dropout
-        assert tr._n_graph_steps > 0
+        losses = tr.fit(seq, epochs=15, verbose=0)['loss']       # full batches: plan steps with dropout
+        assert tr._n_plan_steps > 0
     for epoch in range(0 if rate else 15):
         tot = 0.0
         for batch, t in seq:
