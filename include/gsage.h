@@ -637,8 +637,10 @@ int gs_link_head_reduce(const void *slab, int n_rows, int E, int64_t B, float *g
  *       (nullable): overwritten
  * act is layer 1's activation, normalize as in gs_sage2_forward.  Partial sums leave the first launch as
  * one row per block in `workspace` (gs_sage2_backward_all_workspace bytes) and are added in row order:
- * bitwise reproducible.  Shapes: gs_sage2_backward_all_supported() != 0 (both feature widths F = 32 or 64,
- * H1 = H2 = 32: a wavefront keeps every sum in registers), else GS_ELIMIT.
+ * bitwise reproducible.  The workspace also holds the roots' layer-0 gradient rows between the kernel's two
+ * passes.  Shapes: gs_sage2_backward_all_supported() != 0 (both feature widths F = 32 or 64, H1 = H2 = 32: a
+ * wavefront keeps the layer-0 sums of one node type in registers, the layer-1 sums in LDS), n0 <= 64 (a lane per
+ * hop-1 head) and n_pairs * (1 + n0) * F < 2^31 (32-bit offsets into the saved tables); else GS_ELIMIT.
  */
 /*
  * adam (nullable argument of gs_sage2_backward_all): the optimizer step of gs_adam_step, applied by the
