@@ -322,6 +322,8 @@ int main() {
         REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, 8, 25, 128, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
         REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, 8, 25, 64, 32, 64, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
         REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, 77, arena, ba, nullptr, nullptr));
+        REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, 8, 65, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));                  // a lane per hop-1 head
+        REFUSED(GS_ELIMIT, gs_sage2_backward_all(&p, (int64_t)1 << 21, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));   // 32-bit row offsets
         REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));   // null tables
         for (int t = 0; t < 2; ++t) {
             p.z[t] = p.w1_self[t] = p.w1_neigh[t] = p.h1[t] = p.x_mean1[t] = p.x_self[t] = p.x_mean[t] = f;
