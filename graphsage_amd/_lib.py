@@ -136,6 +136,24 @@ class AdamUpdate(_c.Structure):
                 ('grad_scale', _c.c_float)]
 
 
+class Sage3Bwd(_c.Structure):
+    """gs_sage3_bwd of include/gsage.h."""
+    _fields_ = [('z', _vp * 2), ('emb', _vp * 2), ('g_emb', _vp * 2),
+                ('targets', _vp), ('head_kernel', _vp), ('head_bias', _vp),
+                ('w2_self', _vp * 2), ('w2_neigh', _vp * 2), ('w1_self', _vp * 2), ('w1_neigh', _vp * 2),
+                ('h0', _vp * 2), ('h1', _vp * 2), ('x_mean0', _vp * 2), ('x_mean1', _vp * 2), ('x_mean2', _vp * 2),
+                ('feat', _vp * 2), ('feat_off', _i64 * 2), ('feat_rows', _i64 * 2), ('row_ids', _vp * 2),
+                ('pred', _vp),
+                ('g_w0_self', _vp * 2), ('g_w0_neigh', _vp * 2), ('g_b0', _vp * 2),
+                ('g_w1_self', _vp * 2), ('g_w1_neigh', _vp * 2), ('g_b1', _vp * 2),
+                ('g_w2_self', _vp * 2), ('g_w2_neigh', _vp * 2), ('g_b2', _vp * 2),
+                ('g_head_kernel', _vp), ('g_head_bias', _vp), ('loss', _vp)]
+
+
+SIGNATURES['gs_sage3_backward_all_supported'] = (_i32, [_i32] * 7)
+SIGNATURES['gs_sage3_backward_all_workspace'] = (_sz, [_i64, _i32, _i32])
+SIGNATURES['gs_sage3_backward_all'] = (_i32, [_c.POINTER(Sage3Bwd), _i64, _i32, _i32, _i32, _i32, _i32, _vp, _sz,
+                                              _c.POINTER(AdamUpdate), _vp])
 SIGNATURES['gs_sage2_backward_all_supported'] = (_i32, [_i32] * 4)
 SIGNATURES['gs_sage2_backward_all_workspace'] = (_sz, [_i64, _i32, _i32, _i32])
 SIGNATURES['gs_sage2_backward_all'] = (_i32, [_c.POINTER(Sage2BwdAll), _i64, _i32, _i32, _i32, _i32, _i32, _i32,

@@ -663,6 +663,120 @@ class Sage2BackwardAll:
                                               upd, stream_handle()), 'gs_sage2_backward_all')
 
 
+def _adam_struct(adam):
+    """gs_adam_update from the dict of ``Sage2BackwardAll.run``; returns (struct or None, what to keep alive)."""
+    if adam is None:
+        return None
+    for name in ('grads', 'params', 'm', 'v'):
+        _dev(adam[name], torch.float32, 'adam[%s]' % name, 1)
+        if adam[name].numel() != adam['grads'].numel():
+            raise ValueError("adam[%s] must have %d elements" % (name, adam['grads'].numel()))
+    lr_dev = adam.get('lr_dev')
+    if lr_dev is not None:
+        _dev(lr_dev, torch.float32, 'adam[lr_dev]')
+    return _lib.AdamUpdate(ptr(adam['grads']), ptr(adam['params']), ptr(adam['m']), ptr(adam['v']),
+                           adam['grads'].numel(), ptr(lr_dev), float(adam.get('lr', 0.0)), float(adam['b1']),
+                           float(adam['b2']), float(adam['eps']), float(adam.get('grad_scale', 1.0)))
+
+
+class Sage3BackwardAll:
+    """A prepared ``gs_sage3_backward_all`` call: the whole backward pass of the three-hop model (32 units per layer)
+    on the layered forward's tables -- two kernels and one reduction.  Dicts keyed 'user' / 'item'.
+
+    saved: z [B, 32], h0, x_mean0, row_ids (layer-0 tables, B (1 + n0 + n0 n1) rows), h1, x_mean1 (layer-1 tables,
+           B (1 + n0) rows), x_mean2 [B, 32], feat = (table, first node id) per type
+    weights: {1: {type: (w_self, w_neigh)}, 2: {...}};  grads[(layer, type)] = (g_w_self, g_w_neigh, g_bias or None)
+    head: as ``Sage2BackwardAll``; fan-outs n0 (hop 1), n1 (hop 2); act: layer 2's activation"""
+
+    def __init__(self, saved, weights, grads, n0, n1, normalize, act, head=None):
+        lib = load()
+        types = ('user', 'item')
+        b = saved['z']['user'].shape[0]
+        f = saved['x_mean0']['user'].shape[1]
+        rows0, rows1 = b * (1 + n0 + n0 * n1), b * (1 + n0)
+        if not lib.gs_sage3_backward_all_supported(f, saved['x_mean0']['item'].shape[1], weights[1]['user'][0].shape[0],
+                                                   2 * weights[1]['user'][0].shape[1], saved['z']['user'].shape[1], int(n0), int(n1)):
+            raise _lib.GsageError("gs_sage3_backward_all does not cover this shape")
+        st = _lib.Sage3Bwd()
+        self._keep = [saved, weights, grads, head]
+        for i, t in enumerate(types):
+            for name, shape in (('z', (b, 32)), ('x_mean2', (b, 32)), ('h1', (rows1, 32)), ('x_mean1', (rows1, 32)),
+                                ('h0', (rows0, 32)), ('x_mean0', (rows0, f))):
+                x = saved[name][t]
+                _dev(x, torch.float32, '%s[%s]' % (name, t), 2)
+                if tuple(x.shape) != shape:
+                    raise ValueError("%s[%s] must be %s (got %s)" % (name, t, shape, tuple(x.shape)))
+                getattr(st, name)[i] = ptr(x)
+            _dev(saved['row_ids'][t], torch.int32, 'row_ids[%s]' % t, 1)
+            if saved['row_ids'][t].numel() != rows0:
+                raise ValueError("row_ids[%s] must have %d entries" % (t, rows0))
+            st.row_ids[i] = ptr(saved['row_ids'][t])
+            table, first = saved['feat'][t]
+            _dev(table, torch.float32, 'feature table[%s]' % t, 2)
+            if table.shape[1] != f:
+                raise ValueError("feature table[%s] must be %d wide" % (t, f))
+            st.feat[i], st.feat_off[i], st.feat_rows[i] = ptr(table), int(first), table.shape[0]
+            for layer, names in ((1, ('w1_self', 'w1_neigh')), (2, ('w2_self', 'w2_neigh'))):
+                for name, w in zip(names, weights[layer][t]):
+                    _dev(w, torch.float32, '%s[%s]' % (name, t), 2)
+                    if tuple(w.shape) != (32, 16):
+                        raise ValueError("%s[%s] must be (32, 16)" % (name, t))
+                    getattr(st, name)[i] = ptr(w)
+            for layer, k in ((0, f), (1, 32), (2, 32)):
+                g_ws, g_wn, g_b = grads[(layer, t)]
+                for name, g, cnt in (('g_w%d_self' % layer, g_ws, k * 16), ('g_w%d_neigh' % layer, g_wn, k * 16), ('g_b%d' % layer, g_b, 32)):
+                    if g is None and name.startswith('g_b'):
+                        continue
+                    _dev(g, torch.float32, '%s[%s]' % (name, t))
+                    if g.numel() != cnt:
+                        raise ValueError("%s[%s] has %d elements, %d needed" % (name, t, g.numel(), cnt))
+                    getattr(st, name)[i] = ptr(g)
+        self._head = head is not None
+        if head is not None:
+            emb, targets, kernel, bias, g_kernel, g_bias, pred, loss = head
+            for name, x, n in (('targets', targets, b), ('pred', pred, b), ('head_kernel', kernel, 64), ('head_bias', bias, 1),
+                               ('g_kernel', g_kernel, 64), ('g_bias', g_bias, 1), ('loss', loss, 1)):
+                _dev(x, torch.float32, name)
+                if x.numel() != n:
+                    raise ValueError("%s must have %d elements (got %d)" % (name, n, x.numel()))
+            for i, t in enumerate(types):
+                _dev(emb[t], torch.float32, 'emb[%s]' % t, 2)
+                if tuple(emb[t].shape) != (b, 32):
+                    raise ValueError("emb[%s] must be %s" % (t, (b, 32)))
+                st.emb[i] = ptr(emb[t])
+            st.targets, st.head_kernel, st.head_bias = ptr(targets), ptr(kernel), ptr(bias)
+            st.g_head_kernel, st.g_head_bias, st.pred, st.loss = ptr(g_kernel), ptr(g_bias), ptr(pred), ptr(loss)
+        need = lib.gs_sage3_backward_all_workspace(b, int(n0), f)
+        self._ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=saved['z']['user'].device)
+        self._st, self._lib = st, lib
+        self._args = (b, int(n0), int(n1), f, int(bool(normalize)), ACT[act])
+        self._b = b
+        self.epoch = _storage_epoch
+
+    def run(self, g_emb=None, targets=None, adam=None):
+        if self.epoch != _storage_epoch:
+            raise _lib.GsageError("parameters were moved to other storage after this call was prepared; prepare it again")
+        if self._head:
+            if targets is not None:
+                _dev(targets, torch.float32, 'targets')
+                if targets.numel() != self._b:
+                    raise ValueError("targets must have %d elements" % self._b)
+                self._st.targets = ptr(targets)
+                self._keep_targets = targets
+        else:
+            for i, t in enumerate(('user', 'item')):
+                _dev(g_emb[t], torch.float32, 'g_emb[%s]' % t, 2)
+                if tuple(g_emb[t].shape) != (self._b, 32):
+                    raise ValueError("g_emb[%s] must be %s" % (t, (self._b, 32)))
+                self._st.g_emb[i] = ptr(g_emb[t])
+            self._keep_g = g_emb
+        self._adam = _adam_struct(adam)
+        self._keep_adam = adam
+        check(self._lib.gs_sage3_backward_all(ctypes.byref(self._st), *self._args, ptr(self._ws), self._ws.numel() * 4,
+                                              None if self._adam is None else ctypes.byref(self._adam), stream_handle()),
+              'gs_sage3_backward_all')
+
+
 def sage2_backward_all_supported(fu, fi, h1, h2):
     return bool(load().gs_sage2_backward_all_supported(int(fu), int(fi), int(h1), int(h2)))
 

@@ -287,7 +287,8 @@ class Trainer:
 
     def _update_in_backward(self):
         eng = self.engine
-        return bool(self.fuse_update and eng is not None and eng.tail_kernel and self.opt.p_flat is not None
+        return bool(self.fuse_update and eng is not None and (eng.tail_kernel or getattr(eng, 'fused_backward3', False))
+                    and self.opt.p_flat is not None
                     and eng.can_update_in_backward(self.bucket.flat, (self.head.kernel.grad, self.head.bias.grad)))
 
     def _adam_args(self, lr=None, lr_dev=None):
@@ -308,7 +309,7 @@ class Trainer:
             eng.backward_head(self.head.kernel, self.head.bias, targets, self.head.kernel.grad, self.head.bias.grad,
                               hs.pred, hs.loss, adam=adam)
             return hs.loss, hs.pred
-        if eng.tail_kernel:
+        if eng.tail_kernel or getattr(eng, 'fused_backward3', False):
             if not (isinstance(targets, torch.Tensor) and targets.is_cuda and targets.dtype == torch.float32
                     and targets.is_contiguous() and targets.numel() == eng.batch):
                 raise ValueError("targets must be a contiguous float32 GPU tensor of %d entries" % eng.batch)
@@ -336,6 +337,7 @@ class Trainer:
                                                self.head.kernel.device)
         eng._wgrad_pairs = None
         eng._wgrad_l0_pair = None
+        eng._bwd3 = None
         eng._bwd_all = None
         return True
 

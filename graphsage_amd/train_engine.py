@@ -98,6 +98,14 @@ class SageTrainEngine(SageForwardEngine):
                 all(m._aggs[0][t].activation == 'relu' for t in _TYPES) and
                 kernels.load().gs_sage_project_wgrad_by_id_supported(f['user'], f['item'], m.dims[1]['user'])):
             self.row_ids = {t: torch.zeros(self.h[0][t].shape[0], dtype=torch.int32, device=dev) for t in _TYPES}
+        # Three hops with 32 units per layer: the whole backward pass on these tables is two kernels and a reduction
+        # (gs_sage3_backward_all); fused_backward3 = False keeps the layer-by-layer launches
+        self.fused_backward3 = bool(
+            self.row_ids is not None and self.n_hops == 3 and
+            all(m.dims[layer][t] == 32 for layer in (1, 2, 3) for t in _TYPES) and
+            all(m._aggs[layer][t].activation == 'relu' for layer in (0, 1) for t in _TYPES) and
+            kernels.load().gs_sage3_backward_all_supported(f['user'], f['item'], 32, 32, 32, self.fanouts[0], self.fanouts[1]))
+        self._bwd3 = None
         # Dropout of the aggregator inputs (models.py:152,165) is drawn inside the one-kernel forward; what that
         # kernel saves are the inputs as they entered the layers, so the own rows are saved as rows (not ids) and
         # the masks carry "active and kept".
@@ -239,11 +247,12 @@ class SageTrainEngine(SageForwardEngine):
         ``head_grads``) are views of ``grads_flat`` that cover all of it."""
         m = self.model
         relu0 = all(m._aggs[0][t].activation == 'relu' for t in _TYPES)
-        if not (self.fused_backward and self._tail_kernel and (self.h1_mask is not None or not relu0)):
+        two = self.fused_backward and self._tail_kernel and (self.h1_mask is not None or not relu0)
+        if not (two or self.fused_backward3):
             return False
         if self._padded_model is not None:
             return False
-        gs = [g for layer in (0, 1) for t in _TYPES for g in self._grads_of(m._aggs[layer][t]) if g is not None] + list(head_grads)
+        gs = [g for layer in range(self.n_hops) for t in _TYPES for g in self._grads_of(m._aggs[layer][t]) if g is not None] + list(head_grads)
         lo, hi = grads_flat.data_ptr(), grads_flat.data_ptr() + grads_flat.numel() * 4
         return (all(lo <= g.data_ptr() and g.data_ptr() + g.numel() * 4 <= hi for g in gs)
                 and sum(g.numel() for g in gs) == grads_flat.numel())
@@ -255,13 +264,43 @@ class SageTrainEngine(SageForwardEngine):
         are summed beside the weight gradients.  Only when ``tail_kernel``.  ``adam`` (see
         ``kernels.Sage2BackwardAll.run``; only when ``can_update_in_backward``): the optimizer step in the
         same reduction."""
+        if self.fused_backward3 and not self.tail_kernel:
+            return self._backward_three(None, None, head=(head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss), adam=adam)
         if not self.tail_kernel:
-            raise kernels._lib.GsageError("backward_head needs the two-hop one-kernel route")
+            raise kernels._lib.GsageError("backward_head needs the two-hop one-kernel route or the three-hop one of 32 units per layer")
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
         return self._backward_walks(None, None, main, head=(head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss),
                                     adam=adam)
+
+    def _backward_three(self, g_user, g_item, head=None, adam=None):
+        """Three hops, 32 units per layer, on the layered forward's tables: a kernel over the seeds, one over the
+        hop-1 nodes (each with its children's rows), one reduction; every weight gradient and, with ``head``, the
+        link head and the loss."""
+        m = self.model
+        key = (kernels.storage_epoch(), head is not None, None if head is None else tuple(x.data_ptr() for x in head[:2] + head[3:]))
+        if self._bwd3 is None or self._bwd3[0] != key:
+            b, n0, n1 = self.batch, self.fanouts[0], self.fanouts[1]
+            rows0, rows1 = b * (1 + n0 + n0 * n1), b * (1 + n0)
+            saved = {'z': self.z, 'h0': self.h[0], 'h1': self.h[1], 'row_ids': self.row_ids, 'feat': self.tables,
+                     'x_mean0': {t: self.x_mean[0][t][:rows0] for t in _TYPES},
+                     'x_mean1': {t: self.x_mean[1][t][:rows1] for t in _TYPES},
+                     'x_mean2': {t: self.x_mean[2][t][:b] for t in _TYPES}}
+            weights = {layer: {t: (m._aggs[layer][t].w_self, m._aggs[layer][t].w_neigh) for t in _TYPES} for layer in (1, 2)}
+            grads = {(layer, t): self._grads_of(m._aggs[layer][t]) for layer in (0, 1, 2) for t in _TYPES}
+            hd = None
+            if head is not None:
+                head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss = head
+                hd = ({'user': self.emb['user'], 'item': self.emb['item']}, targets, head_kernel, head_bias, g_kernel, g_bias, pred, loss)
+            self._bwd3 = (key, kernels.Sage3BackwardAll(saved, weights, grads, n0, n1, m.normalize == "l2",
+                                                        m._aggs[2]['user'].activation, head=hd))
+        if head is not None:
+            self._bwd3[1].run(targets=head[2], adam=adam)
+        else:
+            self._bwd3[1].run(g_emb={'user': g_user.contiguous(), 'item': g_item.contiguous()}, adam=adam)
+        if self._padded_model is not None:
+            self._padded_model.scatter_grads()
 
     def _backward_walks(self, g_user, g_item, main, head=None, adam=None):
         """Two hops on the one-kernel forward's tables: one launch takes the embedding
@@ -411,6 +450,8 @@ class SageTrainEngine(SageForwardEngine):
             self._side = torch.cuda.Stream()
         if self.tail_kernel:
             return self._backward_walks(g_user, g_item, main)
+        if self.fused_backward3:
+            return self._backward_three(g_user, g_item)
         streams = {'user': main, 'item': self._side}
         g_emb = {'user': g_user.contiguous(), 'item': g_item.contiguous()}
         g_out = {}

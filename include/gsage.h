@@ -674,6 +674,44 @@ typedef struct gs_sage2_bwd_all {
     float *g_head_kernel, *g_head_bias, *loss;
 } gs_sage2_bwd_all;
 
+/*
+ * The same for THREE hops with 32 units per layer (models.py:146-190 with three layers; train_movielens.py:183-189), on
+ * the tables the layered forward pass saved: a kernel over the seeds (head and loss or the given embedding gradients,
+ * l2 normalisation, layers 2 and 1 at the seed, the seed's layer-0 row), a kernel over the hop-1 nodes (layer 1 at the
+ * node, its own layer-0 row, and the layer-0 rows of its n1 children, whose gradient is one row under n1 relu
+ * masks), one reduction (optionally with the Adam step, as above).  No gradient of an activation is written
+ * except two 128-byte rows per seed.  Tables per node type t, rows in this order (o = the other type):
+ *   layer-0 tables (h0 [.., 32], x_mean0 [.., F], row_ids [..]):  [0, B) the seeds of t; [B, B + B n0) the hop-1
+ *       nodes of t, row B + p n0 + j below seed p of o; then the hop-2 nodes of t, row B (1 + n0) + (p n0 + j) n1 + k
+ *       below seed p of t
+ *   layer-1 tables (h1, x_mean1 [.., 32]):  [0, B) seeds, [B, B + B n0) hop-1 nodes;   x_mean2, z, emb [B, 32]: seeds
+ *   h0 / h1: the layers' outputs after relu;  x_mean*: the neighbor means the layers read;  row_ids: the node id of
+ *   every layer-0 row (own rows are read from feat, feat_rows rows whose first holds node feat_off; ids outside count
+ *   as rows of zeros)
+ * act is layer 2's activation; weights w1_*, w2_* [32, 16]; gradients g_w0_* [F, 16], g_w1_*, g_w2_* [32, 16], g_b*
+ * [32] (nullable).  Shapes: gs_sage3_backward_all_supported() != 0 (F = 32 or 64 for both node types, 32 units in
+ * all three layers, n1 <= 32) and n_pairs (1 + n0 + n0 n1) F < 2^31; else GS_ELIMIT.
+ */
+typedef struct gs_sage3_bwd {
+    const float *z[2], *emb[2], *g_emb[2];
+    const float *targets, *head_kernel, *head_bias;
+    const float *w2_self[2], *w2_neigh[2], *w1_self[2], *w1_neigh[2];
+    const float *h0[2], *h1[2], *x_mean0[2], *x_mean1[2], *x_mean2[2];
+    const float *feat[2];
+    int64_t feat_off[2], feat_rows[2];
+    const int32_t *row_ids[2];
+    float *pred;
+    float *g_w0_self[2], *g_w0_neigh[2], *g_b0[2];
+    float *g_w1_self[2], *g_w1_neigh[2], *g_b1[2];
+    float *g_w2_self[2], *g_w2_neigh[2], *g_b2[2];
+    float *g_head_kernel, *g_head_bias, *loss;
+} gs_sage3_bwd;
+
+int gs_sage3_backward_all_supported(int Fu, int Fi, int H1, int H2, int H3, int n0, int n1);
+size_t gs_sage3_backward_all_workspace(int64_t n_pairs, int n0, int F);
+int gs_sage3_backward_all(const gs_sage3_bwd *p, int64_t n_pairs, int n0, int n1, int F, int normalize, int act,
+                          void *workspace, size_t workspace_bytes, const gs_adam_update *adam, void *stream);
+
 int gs_sage2_backward_all_supported(int Fu, int Fi, int H1, int H2);
 size_t gs_sage2_backward_all_workspace(int64_t n_pairs, int F, int H1, int H2);
 int gs_sage2_backward_all(const gs_sage2_bwd_all *p, int64_t n_pairs, int n0, int F, int H1, int H2,

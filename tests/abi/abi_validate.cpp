@@ -360,6 +360,48 @@ int main() {
         REFUSED(GS_EINVAL, gs_sage2_backward_all(&p, 8, 25, 64, 32, 32, 1, GS_ACT_LINEAR, arena, ba, nullptr, nullptr));
     }
 
+    // ---- the whole three-hop backward pass (32 units per layer) ----
+    EXPECT(gs_sage3_backward_all_supported(64, 64, 32, 32, 32, 25, 10) == 1 && gs_sage3_backward_all_supported(32, 32, 32, 32, 32, 1, 32) == 1);
+    EXPECT(gs_sage3_backward_all_supported(64, 32, 32, 32, 32, 25, 10) == 0 && gs_sage3_backward_all_supported(64, 64, 32, 64, 32, 25, 10) == 0 &&
+           gs_sage3_backward_all_supported(128, 128, 32, 32, 32, 25, 10) == 0 && gs_sage3_backward_all_supported(64, 64, 32, 32, 32, 25, 33) == 0);
+    EXPECT(gs_sage3_backward_all_workspace(0, 25, 64) == 0 && gs_sage3_backward_all_workspace(8, 25, 128) == 0);
+    const size_t b3 = gs_sage3_backward_all_workspace(4096, 25, 64);
+    {
+        const size_t row = 2 * (2 * 64 * 16 + 32) + 4 * 32 + 66 + 4 * 1024;
+        EXPECT(b3 == ((size_t)(256 + 256) * row + (size_t)6 * 4096 * 32 + (size_t)2 * 4096 * 25 * 32) * 4);
+        gs_sage3_bwd p{};
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(nullptr, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 0, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 0, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));
+        REFUSED(GS_ELIMIT, gs_sage3_backward_all(&p, 8, 25, 10, 128, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));
+        REFUSED(GS_ELIMIT, gs_sage3_backward_all(&p, 8, 25, 33, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, 77, arena, b3, nullptr, nullptr));
+        REFUSED(GS_ELIMIT, gs_sage3_backward_all(&p, (int64_t)1 << 18, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));   // 32-bit row offsets
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));   // null tables
+        for (int t = 0; t < 2; ++t) {
+            p.z[t] = p.g_emb[t] = p.w2_self[t] = p.w2_neigh[t] = p.w1_self[t] = p.w1_neigh[t] = f;
+            p.h0[t] = p.h1[t] = p.x_mean0[t] = p.x_mean1[t] = p.x_mean2[t] = p.feat[t] = f;
+            p.row_ids[t] = i32;
+        }
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));   // feat_rows
+        p.feat_rows[0] = p.feat_rows[1] = 100;
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 4096, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3 - 4, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, nullptr, b3, nullptr, nullptr));
+        p.targets = f;                                           // the head form needs emb, head weights and outputs
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));
+        p.emb[0] = p.emb[1] = f;
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));
+        p.targets = nullptr;
+        gs_adam_update ad{};
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, &ad, nullptr));       // empty
+        ad.grads = f; ad.params = ad.m = ad.v = f; ad.n = 16;
+        p.g_w2_self[0] = reinterpret_cast<float *>(arena + 3072);                                                     // outside grads[0 .. n)
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, &ad, nullptr));
+        p.g_w2_self[0] = nullptr;
+        p.x_mean0[1] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(f) + 4);                        // not 16-byte aligned
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));
+    }
+
     // ---- link head, optimizer, staging ----
     EXPECT(gs_link_head_workspace(-1, 32) == 0 && gs_link_head_workspace(4096, 32) == (size_t)256 * 66 * 4);
     ACCEPTED(gs_link_head_fwd(nullptr, nullptr, 0, 32, nullptr, nullptr, nullptr, nullptr));

@@ -113,7 +113,9 @@ def test_short_run_learns(cuda, rate):
                                         # widths take the backward route without paired weight gradients
                                         ([6, 3], [64, 64], 64), ([6, 3], [64, 64], 32), ([4, 2], [64, 64], 128),
                                         ([5, 2], [32, 32], (64, 32)), ([5, 2], [32, 32], (32, 64)),
-                                        ([5, 2], [64, 32], 64), ([5, 2], [32, 64], 64)])
+                                        ([5, 2], [64, 32], 64), ([5, 2], [32, 64], 64),
+                                        # three hops of 32 units: the two-kernel backward pass on the layered tables
+                                        ([5, 3, 2], [32, 32, 32], 64), ([4, 6, 3], [32, 32, 32], 32), ([2, 17, 2], [32, 32, 32], 64)])
 def test_plan_engine_step_equals_autograd_step(cuda, ns, sizes, f):
     """The static training plan (fused forward with saved activations + kernel
     backward) produces the same loss, gradients and updated weights as the
@@ -649,6 +651,37 @@ def test_optimizer_step_inside_the_backward_reduction_equals_the_separate_launch
     assert float((m0 - m1).abs().max()) <= 1e-6 * float(m1.abs().max())
     assert float((v0 - v1).abs().max()) <= 1e-6 * float(v1.abs().max())
     assert float((p0 - out[0][1]).abs().max()) == 0 and l0[2] < l0[0] + 1e-3
+
+
+@pytest.mark.parametrize('ns,f', [([5, 3, 2], 64), ([3, 10, 4], 32)])
+def test_three_hop_backward_in_two_kernels_equals_the_layer_by_layer_launches(cuda, ns, f):
+    """Three hops, 32 units per layer: a step with the backward pass as a kernel over the seeds, a kernel over the
+    hop-1 nodes and one reduction, against the layer-by-layer launches on the same tables: same loss, same gradients
+    up to the order of the sums; the two-kernel form repeats its bits, and with Adam inside its reduction the
+    weights equal those of the separate update."""
+    from graphsage_amd.train import LinkHead
+    g, links, targets = _toy(5, fu=f, fi=f)
+    b, sizes = 48, [32, 32, 32]
+    out = []
+    for fused, fuse_update in ((True, True), (False, True), (True, False), (True, True)):
+        gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+        model = ga.GraphSAGE(sizes, gen, seed=11)
+        model.build()
+        tr = Trainer(model, head=LinkHead(sizes[-1], cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
+        assert tr.engine.fused_backward3 and not tr.engine.tail_kernel
+        tr.engine.fused_backward3 = fused
+        tr.fuse_update = fuse_update
+        lk = np.asarray(links[:b])
+        seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+        loss, pred = tr.step_device(seeds, torch.from_numpy(targets[:b]).to(cuda),
+                                    torch.arange(2 * b, dtype=torch.int64, device=cuda), rng_seed=9)
+        out.append((float(loss), tr.bucket.flat.clone(), tr.opt.p_flat.clone(), pred.clone()))
+    assert abs(out[0][0] - out[1][0]) <= 1e-6 * max(1.0, abs(out[1][0]))
+    assert float((out[0][3] - out[1][3]).abs().max()) < 1e-6
+    scale = float(out[1][1].abs().max())
+    assert scale > 0 and float((out[0][1] - out[1][1]).abs().max()) <= 3e-6 * scale
+    assert torch.equal(out[0][1], out[3][1]) and torch.equal(out[0][2], out[3][2]) and out[0][0] == out[3][0]
+    assert torch.equal(out[0][1], out[2][1]) and torch.equal(out[0][2], out[2][2])      # Adam inside / after the reduction
 
 
 def test_stage_batch_copies_inputs_and_rate_in_one_launch(cuda):
