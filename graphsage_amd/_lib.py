@@ -107,7 +107,25 @@ class Sage2Saved(_c.Structure):
 class Sage2Subtrees(_c.Structure):
     """gs_sage2_subtrees of include/gsage.h."""
     _fields_ = [('roots_per_walk', _i32), ('tape_len', _i64), ('tape_off_hop2', _i64), ('tape_off_hop3', _i64),
-                ('out_h0', _vp), ('seeds', _vp), ('out_hop1', _vp)]
+                ('out_h0', _vp), ('seeds', _vp), ('out_hop1', _vp),
+                ('sv_x_mean0_hop2', _vp * 2), ('sv_mask_hop2', _vp * 2), ('sv_x_mean0_hop1', _vp * 2),
+                ('sv_x_mean1_hop1', _vp * 2)]
+
+
+class Sage3SeedsSaved(_c.Structure):
+    """gs_sage3_seeds_saved of include/gsage.h."""
+    _fields_ = [('x_mean0', _vp * 2), ('h0', _vp * 2), ('x_mean1', _vp * 2), ('h1', _vp * 2), ('x_mean2', _vp * 2),
+                ('z', _vp * 2)]
+
+
+class Sage3BwdHop1(_c.Structure):
+    """gs_sage3_bwd_hop1 of include/gsage.h."""
+    _fields_ = [('h0', _vp * 2), ('h1', _vp * 2), ('x_mean0', _vp * 2), ('x_mean1', _vp * 2), ('ids', _vp * 2)]
+
+
+class Sage3BwdHop2(_c.Structure):
+    """gs_sage3_bwd_hop2 of include/gsage.h."""
+    _fields_ = [('h0', _vp * 2), ('mask', _vp * 2), ('x_mean0', _vp * 2), ('ids', _vp * 2)]
 
 
 class Sage2L0Mask(_c.Structure):
@@ -147,7 +165,8 @@ class Sage3Bwd(_c.Structure):
                 ('g_w0_self', _vp * 2), ('g_w0_neigh', _vp * 2), ('g_b0', _vp * 2),
                 ('g_w1_self', _vp * 2), ('g_w1_neigh', _vp * 2), ('g_b1', _vp * 2),
                 ('g_w2_self', _vp * 2), ('g_w2_neigh', _vp * 2), ('g_b2', _vp * 2),
-                ('g_head_kernel', _vp), ('g_head_bias', _vp), ('loss', _vp)]
+                ('g_head_kernel', _vp), ('g_head_bias', _vp), ('loss', _vp),
+                ('hop1', _c.POINTER(Sage3BwdHop1)), ('hop2', _c.POINTER(Sage3BwdHop2))]
 
 
 SIGNATURES['gs_sage3_backward_all_supported'] = (_i32, [_i32] * 7)
@@ -173,6 +192,9 @@ SIGNATURES['gs_sage2_forward_subtrees'] = (_i32, [_vp, _vp, _i64, _vp, _i64, _i3
 SIGNATURES['gs_sage3_seeds_supported'] = (_i32, [_i32] * 6)
 SIGNATURES['gs_sage3_seeds_forward'] = (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp, _vp] +
                                         [_c.POINTER(SageWeights)] * 6 + [_i32, _i32, _i32, _i32, _i32, _vp, _vp])
+SIGNATURES['gs_sage3_seeds_forward_saving'] = (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp, _vp] +
+                                               [_c.POINTER(SageWeights)] * 6 + [_i32, _i32, _i32, _i32, _i32, _vp,
+                                                                                _c.POINTER(Sage3SeedsSaved), _vp])
 SIGNATURES['gs_sage2_backward_tail'] = (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32,
                                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(Sage2L0Mask), _vp])
 

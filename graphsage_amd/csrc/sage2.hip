@@ -88,6 +88,9 @@ struct Sage2Args {
     // seed walks, slot = the root's position below its seed) and written to hop1_out instead of read from seeds.
     const int32_t *seeds0;
     int32_t *hop1_out;
+    // subtree mode, training (SAVE): sv_x_mean / sv_h1_mask hold, by node type, the neighbor means and the relu-mask
+    // words of the heads (row = root index within its type * n0 + head); and by the roots' type, one row per root:
+    float *sv_root_mean0[2], *sv_root_mean1[2];       // the layer-0 / layer-1 neighbor means of the roots
 };
 
 template <int FU, int FI, int HH1, int HH2>
@@ -526,16 +529,16 @@ __device__ __forceinline__ void tile_means(const RowTable<BUF> &tabT, const int3
 // and slot offsets are per root).  The arithmetic of walk_body one hop down (sampler hops 1 and 2, slots shifted by
 // the root's position below its seed, relu after layer 1, no normalisation); the neighbor sum of a root is taken
 // over its heads in list order.
-template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, int G>
+template <int FT, int FO, int HH1, int HH2, int LDA, int LDH, bool BUF, int G, bool SAVE>
 __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int n_valid, int side, int lane,
                                            int32_t rootv, int64_t rav, int64_t rbv, unsigned long long walkv,
                                            float *A, float *H1t, int32_t *s_ids,
                                            const float *W0s_T, const float *W0n_T, const float *W0s_O, const float *W0n_O,
                                            const float *W1s_T, const float *W1n_T,
                                            const float *b0_T, const float *b0_O, const float *b1_T) {
-    constexpr bool SAVE = false;
     constexpr int NT1 = HH1 / 16, NT2 = HH2 / 16, H1 = 2 * HH1, H2 = 2 * HH2;
     constexpr int FTV = FT / 4, FOV = FO / 4, H1V = H1 / 4;
+    static_assert(!SAVE || H1 == 32, "the saved relu masks are one word per row");
     constexpr int RS_N = (G * FOV + 63) / 64, RT_N = (G * FTV + 63) / 64;
     constexpr int L1_N = (G * H1V + 63) / 64;
     static_assert(G >= 1 && G <= 16, "the roots are rows 0 .. G-1 of one 16-row tile");
@@ -548,8 +551,9 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
     int32_t *hop1 = s_ids, *hop2 = s_ids + NH;
     int wl = lane;
     asm volatile("" : "+v"(wl));            // keeps the weight-fragment reads inside the group loop
-    const long long sv_h1row = 0, pair = 0; // (names the shared tile loop mentions in its saving branches)
-    (void)sv_h1row; (void)pair;
+    // saving: the group's first root within its node type, and the heads that belong to roots that exist
+    const long long sv_root0 = w0 - (side ? 0 : a.n_pairs);
+    const int nh_valid = n_valid * n0;
 
     // lane g < G carries root g: id (-1 / -2: none), CSR row bounds, walk id; position below its seed walk
     const long long my_w = w0 + min(lane, n_valid - 1);          // (lanes past the valid roots repeat the last one)
@@ -655,9 +659,10 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
         if (kShort && 2 * n1 <= kUnroll) tile_means<FT, LDA, BUF, kShort ? 2 * KH : KH, kUnroll / 2>(tabT, hop2, j0, np, n1, lane, A);
         else tile_means<FT, LDA, BUF, KH, kUnroll>(tabT, hop2, j0, np, n1, lane, A);
         wave_lds_fence();
-        if (SAVE) {                          // the tile of neighbor means, out of LDS: np consecutive table rows
-            float *dst = a.sv_x_mean[1 - side] + (size_t)(sv_h1row + j0) * FT;
-            for (int i = lane; i < np * FTV; i += 64)
+        const int nv = min(np, nh_valid - j0);                   // rows of this tile the saved tables have (may be < 1)
+        if (SAVE) {                          // the tile of neighbor means, out of LDS: nv consecutive table rows
+            float *dst = a.sv_x_mean[1 - side] + (size_t)(sv_root0 * n0 + j0) * FT;
+            for (int i = lane; i < nv * FTV; i += 64)
                 stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(A + (i / FTV) * LDA + 4 * (i % FTV)));
         }
         f32x4 acc_s[NT1], acc_n[NT1];
@@ -669,8 +674,6 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
         for (int pass = 0; pass < NPASS_O; ++pass) {
             const int rr = pass * RP_O + lane / FOV, c = lane % FOV;
             *reinterpret_cast<float4 *>(A + rr * LDA + 4 * c) = own[pass];
-            if (SAVE && a.sv_x_self[1 - side] && rr < np)
-                stream_store(a.sv_x_self[1 - side] + (size_t)(sv_h1row + j0 + rr) * FO + 4 * c, own[pass]);
         }
         wave_lds_fence();
         mma_tile<FO, NT1>(A, LDA, W0s_O, wl, r, q, acc_s);
@@ -699,6 +702,21 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
             }
         }
         wave_lds_fence();
+        if constexpr (SAVE) {
+            // the heads' rows are read back only for their relu masks: one word per row (bit c: column c > 0), two rows
+            // per ballot; lane t keeps the words of rows 2t and 2t + 1
+            uint32_t w_lo = 0, w_hi = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const unsigned long long bits = __ballot(A[(2 * t + (lane >> 5)) * LDA + (lane & 31)] > 0.f);
+                if (lane == t) { w_lo = (uint32_t)bits; w_hi = (uint32_t)(bits >> 32); }
+            }
+            uint32_t *mw = a.sv_h1_mask[1 - side] + (size_t)(sv_root0 * n0 + j0) + 2 * lane;    // (8-byte aligned: kGroup and 16 are even)
+            if (lane < 8) {
+                if (2 * lane + 1 < nv) *reinterpret_cast<uint2 *>(mw) = make_uint2(w_lo, w_hi);
+                else if (2 * lane < nv) *mw = w_lo;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < L1_N; ++k) {
             const int idx = k * 64 + lane, g = idx / H1V, c = idx % H1V;
@@ -720,9 +738,12 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
 #pragma unroll
         for (int k = 0; k < RS_N; ++k) {
             const int idx = k * 64 + lane;
-            if (idx < G * FOV)
-                *reinterpret_cast<float4 *>(A + (idx / FOV) * LDA + 4 * (idx % FOV)) =
-                    make_float4(rs[k].x / d0, rs[k].y / d0, rs[k].z / d0, rs[k].w / d0);
+            if (idx < G * FOV) {
+                const float4 mean = make_float4(rs[k].x / d0, rs[k].y / d0, rs[k].z / d0, rs[k].w / d0);
+                *reinterpret_cast<float4 *>(A + (idx / FOV) * LDA + 4 * (idx % FOV)) = mean;
+                if (SAVE && idx / FOV < n_valid)
+                    stream_store(a.sv_root_mean0[side] + (size_t)(sv_root0 + idx / FOV) * FO + 4 * (idx % FOV), mean);
+            }
         }
         wave_lds_fence();
         f32x4 acc_s[NT1], acc_n[NT1];
@@ -759,7 +780,9 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
             const int idx = k * 64 + lane;
             if (idx < G * H1V) {
                 const int g = idx / H1V, c = idx % H1V;
-                *reinterpret_cast<float4 *>(A + g * LDA + 4 * c) = make_float4(hs[k].x / d0, hs[k].y / d0, hs[k].z / d0, hs[k].w / d0);
+                const float4 mean = make_float4(hs[k].x / d0, hs[k].y / d0, hs[k].z / d0, hs[k].w / d0);
+                *reinterpret_cast<float4 *>(A + g * LDA + 4 * c) = mean;
+                if (SAVE && g < n_valid) stream_store(a.sv_root_mean1[side] + (size_t)(sv_root0 + g) * H1 + 4 * c, mean);
                 if (a.out_h0 && g < n_valid)     // the root's layer-0 output (the layer above reads it as a neighbor's)
                     *reinterpret_cast<float4 *>(a.out_h0 + (size_t)(w0 + g) * H1 + 4 * c) = *reinterpret_cast<const float4 *>(H1t + g * LDH + 4 * c);
             }
@@ -895,10 +918,10 @@ void sage2_kernel(const Sage2Args a) {
             fetch(grp + stride, nrv, nrav, nrbv, nwkv);
             const int n_valid = (int)min((long long)kGroup, a.n_pairs - grp * kGroup);
             if (side == 0)
-                group_body<FU, FI, HH1, HH2, LDA, LDH, BUF, kGroup>(a, base + grp * kGroup, n_valid, 0, lane, rv, rav, rbv, wkv, A, H1t, s_ids,
+                group_body<FU, FI, HH1, HH2, LDA, LDH, BUF, kGroup, SAVE>(a, base + grp * kGroup, n_valid, 0, lane, rv, rav, rbv, wkv, A, H1t, s_ids,
                                                                     w0s_u, w0n_u, w0s_i, w0n_i, w1s, w1n, bias, bias + H1, bias + 2 * H1);
             else
-                group_body<FI, FU, HH1, HH2, LDA, LDH, BUF, kGroup>(a, base + grp * kGroup, n_valid, 1, lane, rv, rav, rbv, wkv, A, H1t, s_ids,
+                group_body<FI, FU, HH1, HH2, LDA, LDH, BUF, kGroup, SAVE>(a, base + grp * kGroup, n_valid, 1, lane, rv, rav, rbv, wkv, A, H1t, s_ids,
                                                                     w0s_i, w0n_i, w0s_u, w0n_u, w1s, w1n, bias + H1, bias, bias + 2 * H1);
             rv = nrv; rav = nrav; rbv = nrbv; wkv = nwkv;
         }
@@ -946,6 +969,10 @@ int launch(const Sage2Args &a, hipStream_t stream) {
     // buffer addressing needs both tables inside a 4 GiB window
     const long long lim = 0xFFFFF000LL;                  // RowTable::kNoRow must lie past the end of both tables
     const bool buf = a.n_rows[0] * FU * 4 < lim && a.n_rows[1] * FI * 4 < lim;
+    if constexpr (HH1 == 16) {
+        if (a.sub_n && a.sv_root_mean0[0])
+            return buf ? launch_one<FU, FI, HH1, HH2, true, true, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, true, true>(a, stream);
+    }
     if (a.sub_n) return buf ? launch_one<FU, FI, HH1, HH2, true, false, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, false, true>(a, stream);
     if (a.sv_z[0] && a.drop_thr)
         return buf ? launch_one<FU, FI, HH1, HH2, true, true, false, true>(a, stream) : launch_one<FU, FI, HH1, HH2, false, true, false, true>(a, stream);
@@ -1026,6 +1053,20 @@ int sage2_forward_impl(const int64_t *indptr, const int32_t *indices, int64_t n_
         a.tape_len = sub->tape_len; a.tape_off0 = sub->tape_off_hop2; a.tape_off1 = sub->tape_off_hop3;
         a.out_h0 = sub->out_h0;
         a.seeds0 = sub->seeds; a.hop1_out = sub->out_hop1;
+        const bool any = sub->sv_x_mean0_hop2[0] || sub->sv_x_mean0_hop2[1] || sub->sv_mask_hop2[0] || sub->sv_mask_hop2[1] ||
+                         sub->sv_x_mean0_hop1[0] || sub->sv_x_mean0_hop1[1] || sub->sv_x_mean1_hop1[0] || sub->sv_x_mean1_hop1[1];
+        if (any) {
+            if (H1 != 32) return gs::fail(GS_ELIMIT, "gs_sage2_forward_subtrees: the saving form has H1 = 32 (got %d)", H1);
+            for (int t = 0; t < 2; ++t) {
+                if (!sub->sv_x_mean0_hop2[t] || !sub->sv_mask_hop2[t] || !sub->sv_x_mean0_hop1[t] || !sub->sv_x_mean1_hop1[t])
+                    return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: the sv_ tables are given all or none");
+                if (!aligned16(sub->sv_x_mean0_hop2[t]) || !aligned16(sub->sv_x_mean0_hop1[t]) || !aligned16(sub->sv_x_mean1_hop1[t]) ||
+                    (reinterpret_cast<uintptr_t>(sub->sv_mask_hop2[t]) & 7))
+                    return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: the sv_ tables must be 16-byte (masks: 8-byte) aligned");
+                a.sv_x_mean[t] = sub->sv_x_mean0_hop2[t]; a.sv_h1_mask[t] = sub->sv_mask_hop2[t];
+                a.sv_root_mean0[t] = sub->sv_x_mean0_hop1[t]; a.sv_root_mean1[t] = sub->sv_x_mean1_hop1[t];
+            }
+        }
         if (sub->seeds && !sub->out_hop1)
             return gs::fail(GS_EINVAL, "gs_sage2_forward_subtrees: seeds given without out_hop1");
         if (sub->seeds && replay && sub->roots_per_walk > sub->tape_len)

@@ -31,10 +31,15 @@ struct Bwd3Args {
     const float *z[2], *emb[2], *g_emb[2];
     const float *targets, *head_kernel, *head_bias;
     const float *w2_self[2], *w2_neigh[2], *w1_self[2], *w1_neigh[2];
-    const float *h0[2], *h1[2], *x_mean0[2], *x_mean1[2], *x_mean2[2];
+    // by node type t: the seeds' rows, the rows of the hop-1 nodes of type t (below seeds of the other type), the rows of
+    // the hop-2 nodes of type t (below seeds of t)
+    const float *h1_seed[2], *x_mean2[2], *h0_seed[2], *x_mean1_seed[2], *x_mean0_seed[2];
+    const float *h1_hop1[2], *h0_hop1[2], *x_mean1_hop1[2], *x_mean0_hop1[2];
+    const float *h0_hop2[2], *x_mean0_hop2[2];
+    const uint32_t *mask_hop2[2];           // instead of h0_hop2 when not NULL: bit c of word i says h0_hop2[i][c] > 0
+    const int32_t *ids_seed[2], *ids_hop1[2], *ids_hop2[2];
     const float *feat[2];
     long long feat_off[2], feat_rows[2];
-    const int32_t *row_ids[2];
     long long n_pairs;
     int n0, n1, normalize, relu;
     float *pred;
@@ -183,8 +188,8 @@ __device__ __forceinline__ void seeds_of_type(const Bwd3Args &a, Sums3<F> &sums,
     const int r = lane & 15, q = lane >> 4, k = lane & 31, half = lane >> 5;
     const long long B = a.n_pairs;
     const float *z = a.z[TT], *emb_u = a.emb[0], *emb_i = a.emb[1], *g_emb = a.g_emb[TT];
-    const float *h1 = a.h1[TT], *h0 = a.h0[TT], *m2 = a.x_mean2[TT], *m1 = a.x_mean1[TT], *xn0 = a.x_mean0[TT], *feat = a.feat[TT];
-    const int32_t *ids = a.row_ids[TT];
+    const float *h1 = a.h1_seed[TT], *h0 = a.h0_seed[TT], *m2 = a.x_mean2[TT], *m1 = a.x_mean1_seed[TT], *xn0 = a.x_mean0_seed[TT], *feat = a.feat[TT];
+    const int32_t *ids = a.ids_seed[TT];
     const long long off = a.feat_off[TT], rows = a.feat_rows[TT];
     float *a_row = a.a_row[TT], *b_row = a.b_row[TT], *root_g = a.root_seed[TT];
     // staged weights: [type][W2s, W2n, W1s, W1n][n][k]
@@ -323,12 +328,12 @@ __device__ __forceinline__ void subtrees_of_type(const Bwd3Args &a, Sums3<F> &su
     const long long B = a.n_pairs;
     const int n0 = a.n0, n1 = a.n1, NS = (n1 + 3) >> 2;
     const long long n_sub = B * n0;                              // subtrees of this side
-    const long long c0 = B * (1 + n0);                           // first hop-2 row of a layer-0 table
     const float *a_row = a.a_row[TT], *b_row = a.b_row[TT];
-    const float *h1 = a.h1[O], *h0r = a.h0[O], *m1 = a.x_mean1[O];
-    const float *h0c = a.h0[TT], *xn_c = a.x_mean0[TT], *feat_c = a.feat[TT];
-    const float *xn_r = a.x_mean0[O], *feat_r = a.feat[O];
-    const int32_t *ids_c = a.row_ids[TT], *ids_r = a.row_ids[O];
+    const float *h1 = a.h1_hop1[O], *h0r = a.h0_hop1[O], *m1 = a.x_mean1_hop1[O];
+    const float *h0c = a.h0_hop2[TT], *xn_c = a.x_mean0_hop2[TT], *feat_c = a.feat[TT];
+    const uint32_t *mk_c = a.mask_hop2[TT];
+    const float *xn_r = a.x_mean0_hop1[O], *feat_r = a.feat[O];
+    const int32_t *ids_c = a.ids_hop2[TT], *ids_r = a.ids_hop1[O];
     const long long off_c = a.feat_off[TT], rows_c = a.feat_rows[TT], off_r = a.feat_off[O], rows_r = a.feat_rows[O];
     float *root_g = a.root_sub[TT];
     const float *w1s = wt + (O * 2 + 0) * kH * kHH, *w1n = w1s + kH * kHH;       // layer 1 at a root: the root type's weights
@@ -336,15 +341,16 @@ __device__ __forceinline__ void subtrees_of_type(const Bwd3Args &a, Sums3<F> &su
     sums.clear_rest();
     sums.clear_layer0(TT);
 
-    struct Sub { float av, bv, h1v, h0v, m1v; int32_t idv; };
+    struct Sub { float av, bv, h1v, h0v, m1v; int32_t idv; uint32_t mwv; };
     auto load_sub = [&](Sub &s, long long i) {
         const long long p = i / n0;
         s.av = a_row[p * kH + k];
         s.bv = b_row[p * kH + k];
-        s.h1v = h1[(B + i) * kH + k];
-        s.h0v = h0r[(B + i) * kH + k];
-        s.m1v = m1[(B + i) * kH + k];
-        s.idv = ids_c[c0 + i * n1 + min(lane, n1 - 1)];          // lane j: child j (n1 <= 64)
+        s.h1v = h1[i * kH + k];
+        s.h0v = h0r[i * kH + k];
+        s.m1v = m1[i * kH + k];
+        s.idv = ids_c[i * n1 + min(lane, n1 - 1)];               // lane j: child j (n1 <= 32)
+        s.mwv = mk_c ? mk_c[i * n1 + min(lane, n1 - 1)] : 0u;
     };
     Sub nxt;
     if (i_first < n_sub) load_sub(nxt, i_first);
@@ -362,15 +368,21 @@ __device__ __forceinline__ void subtrees_of_type(const Bwd3Args &a, Sums3<F> &su
             for (int u = 0; u < U; ++u) {
                 const int g = g0 + u;
                 const int j = min(4 * g + q, n1 - 1);             // (a slot past n1 reads child n1-1 in place, weight 0)
-                const unsigned row = (unsigned)(c0 + i * n1) + j; // (rows * F < 2^31: checked by the host)
+                const unsigned row = (unsigned)(i * n1) + j;      // (rows * F < 2^31: checked by the host)
                 long long own = (long long)__shfl(s.idv, j, 64) - off_c;
                 const bool ok = (unsigned long long)own < (unsigned long long)rows_c;
                 if (!ok) own = 0;
                 okbits |= (ok ? 1u : 0u) << u;
                 xs[u].load(feat_c + own * F + V * r);
                 xn[u].load(xn_c + (row * F + V * r));
-                ml[u] = h0c[row * kH + r];
-                mh[u] = h0c[row * kH + 16 + r];
+                if (mk_c) {                                       // (uniform) the mask word of the row, from the lane that read it
+                    const uint32_t mw = (uint32_t)__shfl((int)s.mwv, j, 64);
+                    ml[u] = (mw >> r) & 1u ? 1.f : 0.f;
+                    mh[u] = (mw >> (16 + r)) & 1u ? 1.f : 0.f;
+                } else {
+                    ml[u] = h0c[row * kH + r];
+                    mh[u] = h0c[row * kH + 16 + r];
+                }
             }
             if (g0 == 0) {
                 // ---- layer 1 at the root, while its children's rows arrive ----
@@ -414,12 +426,12 @@ __device__ __forceinline__ void subtrees_of_type(const Bwd3Args &a, Sums3<F> &su
         const long long iq = i0 + q * i_step;
         const bool live = iq < n_sub;
         const long long i = live ? iq : i0;
-        long long own = (long long)ids_r[B + i] - off_r;
+        long long own = (long long)ids_r[i] - off_r;
         const bool ok = (unsigned long long)own < (unsigned long long)rows_r;
         if (!ok) own = 0;
         Row<V> xs, xn;
         xs.load(feat_r + own * F + V * r);
-        xn.load(xn_r + (B + i) * F + V * r);
+        xn.load(xn_r + i * F + V * r);
         const float gs_ = root_g[i * kH + r], gn_ = root_g[i * kH + 16 + r];
         const float bs = live ? gs_ : 0.f, bn = live ? gn_ : 0.f;
 #pragma unroll
@@ -494,18 +506,40 @@ extern "C" int gs_sage3_backward_all(const gs_sage3_bwd *p, int64_t n_pairs, int
         return gs::fail(GS_ELIMIT, "%s: n_pairs=%lld too large (the saved tables are indexed with 32 bits)", who, (long long)n_pairs);
     const bool head = p->targets != nullptr;
     Bwd3Args a{};
+    const size_t hop1_rows = (size_t)n_pairs * n0;
+    const gs_sage3_bwd_hop1 *h1p = p->hop1;
+    const gs_sage3_bwd_hop2 *h2p = p->hop2;
     for (int t = 0; t < 2; ++t) {
         if (!p->z[t] || !p->w2_self[t] || !p->w2_neigh[t] || !p->w1_self[t] || !p->w1_neigh[t] || !p->h0[t] || !p->h1[t] ||
             !p->x_mean0[t] || !p->x_mean1[t] || !p->x_mean2[t] || !p->feat[t] || !p->row_ids[t])
             return gs::fail(GS_EINVAL, "%s: null table or weight pointer (type %d)", who, t);
         if (head ? !p->emb[t] : !p->g_emb[t]) return gs::fail(GS_EINVAL, "%s: %s is null (type %d)", who, head ? "emb" : "g_emb", t);
         if (p->feat_rows[t] < 1) return gs::fail(GS_EINVAL, "%s: feat_rows[%d]=%lld", who, t, (long long)p->feat_rows[t]);
-        if ((reinterpret_cast<uintptr_t>(p->feat[t]) | reinterpret_cast<uintptr_t>(p->x_mean0[t])) & 15)
-            return gs::fail(GS_EINVAL, "%s: feat / x_mean0 must be 16-byte aligned", who);
+        if (h1p && (!h1p->h0[t] || !h1p->h1[t] || !h1p->x_mean0[t] || !h1p->x_mean1[t] || !h1p->ids[t]))
+            return gs::fail(GS_EINVAL, "%s: hop1 has a null table (type %d)", who, t);
+        if (h2p && (!h2p->x_mean0[t] || !h2p->ids[t] || (!h2p->h0[t] && !h2p->mask[t])))
+            return gs::fail(GS_EINVAL, "%s: hop2 needs x_mean0, ids and h0 or mask (type %d)", who, t);
         a.z[t] = p->z[t]; a.emb[t] = p->emb[t]; a.g_emb[t] = p->g_emb[t];
         a.w2_self[t] = p->w2_self[t]; a.w2_neigh[t] = p->w2_neigh[t]; a.w1_self[t] = p->w1_self[t]; a.w1_neigh[t] = p->w1_neigh[t];
-        a.h0[t] = p->h0[t]; a.h1[t] = p->h1[t]; a.x_mean0[t] = p->x_mean0[t]; a.x_mean1[t] = p->x_mean1[t]; a.x_mean2[t] = p->x_mean2[t];
-        a.feat[t] = p->feat[t]; a.feat_off[t] = p->feat_off[t]; a.feat_rows[t] = p->feat_rows[t]; a.row_ids[t] = p->row_ids[t];
+        a.x_mean2[t] = p->x_mean2[t];
+        a.h1_seed[t] = p->h1[t]; a.x_mean1_seed[t] = p->x_mean1[t]; a.h0_seed[t] = p->h0[t]; a.x_mean0_seed[t] = p->x_mean0[t];
+        a.ids_seed[t] = p->row_ids[t];
+        a.h1_hop1[t] = h1p ? h1p->h1[t] : p->h1[t] + (size_t)n_pairs * kH;
+        a.x_mean1_hop1[t] = h1p ? h1p->x_mean1[t] : p->x_mean1[t] + (size_t)n_pairs * kH;
+        a.h0_hop1[t] = h1p ? h1p->h0[t] : p->h0[t] + (size_t)n_pairs * kH;
+        a.x_mean0_hop1[t] = h1p ? h1p->x_mean0[t] : p->x_mean0[t] + (size_t)n_pairs * F;
+        a.ids_hop1[t] = h1p ? h1p->ids[t] : p->row_ids[t] + n_pairs;
+        // (without hop1 / hop2 the rows follow the seeds' in the whole tables)
+        const size_t above = h1p ? 0 : (size_t)n_pairs + hop1_rows;
+        a.x_mean0_hop2[t] = h2p ? h2p->x_mean0[t] : (h1p ? nullptr : p->x_mean0[t] + above * F);
+        a.ids_hop2[t] = h2p ? h2p->ids[t] : (h1p ? nullptr : p->row_ids[t] + above);
+        a.mask_hop2[t] = h2p ? h2p->mask[t] : nullptr;
+        a.h0_hop2[t] = h2p ? h2p->h0[t] : (h1p ? nullptr : p->h0[t] + above * kH);
+        if (!a.x_mean0_hop2[t]) return gs::fail(GS_EINVAL, "%s: hop1 is given without hop2", who);
+        if ((reinterpret_cast<uintptr_t>(p->feat[t]) | reinterpret_cast<uintptr_t>(a.x_mean0_seed[t]) |
+             reinterpret_cast<uintptr_t>(a.x_mean0_hop1[t]) | reinterpret_cast<uintptr_t>(a.x_mean0_hop2[t])) & 15)
+            return gs::fail(GS_EINVAL, "%s: feat / x_mean0 must be 16-byte aligned", who);
+        a.feat[t] = p->feat[t]; a.feat_off[t] = p->feat_off[t]; a.feat_rows[t] = p->feat_rows[t];
     }
     if (head && (!p->head_kernel || !p->head_bias || !p->pred || !p->g_head_kernel || !p->g_head_bias || !p->loss))
         return gs::fail(GS_EINVAL, "%s: the head needs head_kernel, head_bias, pred, g_head_kernel, g_head_bias and loss", who);

@@ -21,7 +21,20 @@ struct Roots3Args {
     const float *ws[3][2], *wn[3][2], *b[3][2];        // by layer and seed type
     int act, normalize;
     float *emb;                                        // [2*n_pairs, H3]
+    // training (all NULL otherwise): by seed type, one row per seed -- the neighbor means the three layers read, the
+    // outputs of layers 0 and 1, layer 2's output before the normalisation
+    float *sv_x_mean0[2], *sv_h0[2], *sv_x_mean1[2], *sv_h1[2], *sv_x_mean2[2], *sv_z[2];
 };
+
+// Rows 0 .. R-1 (4*V floats each) of an LDS tile to rows s0 .. of a saved table (those below n_pairs).
+template <int V>
+__device__ __forceinline__ void save_rows(float *table, long long s0, long long n_pairs, const float *src, int ld, int lane) {
+    for (int i = lane; i < kSeedsPerWave * V; i += 64) {
+        const int g = i / V, c = i % V;
+        if (s0 + g < n_pairs)
+            *reinterpret_cast<float4 *>(table + (size_t)(s0 + g) * (4 * V) + 4 * c) = *reinterpret_cast<const float4 *>(src + g * ld + 4 * c);
+    }
+}
 
 // Sums of the n rows (4*V floats each) of R heads, divided by n, into rows 0 .. R-1 of A.  A load instruction
 // covers 64 / V rows; with at least R of them a head's rows are split over GPS lane groups, whose partial sums
@@ -77,6 +90,7 @@ __device__ __forceinline__ void seeds_body(const Roots3Args &a, long long tile, 
     asm volatile("" : "+v"(wl));
     const long long s0 = tile * R;                     // first seed of the tile, within its type
     const long long row0 = (long long)side * a.n_pairs + s0;       // its row in the seed-ordered arrays
+    const bool save = a.sv_z[0] != nullptr;
 
     wave_lds_fence();                                  // the previous tile's readers are done
     for (int i = lane; i < R * n0; i += 64) {
@@ -100,6 +114,7 @@ __device__ __forceinline__ void seeds_body(const Roots3Args &a, long long tile, 
         return tabO.load(ok && id >= 0, (unsigned)(id - offO), (unsigned)c * 16u, FO * 4);
     });
     wave_lds_fence();
+    if (save) save_rows<FOV>(a.sv_x_mean0[side], s0, a.n_pairs, A, LDA, lane);
     {
         f32x4 acc_s[NT1], acc_n[NT1];
 #pragma unroll
@@ -123,6 +138,7 @@ __device__ __forceinline__ void seeds_body(const Roots3Args &a, long long tile, 
                 }
         }
         wave_lds_fence();
+        if (save) save_rows<H1V>(a.sv_h0[side], s0, a.n_pairs, Hs, LDS_H, lane);
     }
 
     // ---- layer 1: neighbors = the hop-1 nodes' layer-0 outputs (consecutive rows) ----
@@ -132,6 +148,7 @@ __device__ __forceinline__ void seeds_body(const Roots3Args &a, long long tile, 
         return want ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     });
     wave_lds_fence();
+    if (save) save_rows<H1V>(a.sv_x_mean1[side], s0, a.n_pairs, A, LDA, lane);
     {
         f32x4 acc_s[NT2], acc_n[NT2];
 #pragma unroll
@@ -153,6 +170,7 @@ __device__ __forceinline__ void seeds_body(const Roots3Args &a, long long tile, 
                 }
         }
         wave_lds_fence();
+        if (save) save_rows<H2V>(a.sv_h1[side], s0, a.n_pairs, Hs, LDS_H, lane);
     }
 
     // ---- layer 2: neighbors = the hop-1 nodes' layer-1 outputs ----
@@ -162,6 +180,7 @@ __device__ __forceinline__ void seeds_body(const Roots3Args &a, long long tile, 
         return want ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     });
     wave_lds_fence();
+    if (save) save_rows<H2V>(a.sv_x_mean2[side], s0, a.n_pairs, A, LDA, lane);
     {
         f32x4 acc_s[NT3], acc_n[NT3];
 #pragma unroll
@@ -183,6 +202,11 @@ __device__ __forceinline__ void seeds_body(const Roots3Args &a, long long tile, 
                 o[1][ct] = acc_n[ct][i] + b2[HH3 + ct * 16 + r];
                 if (a.act == GS_ACT_RELU) { o[0][ct] = fmaxf(o[0][ct], 0.f); o[1][ct] = fmaxf(o[1][ct], 0.f); }
                 ss += o[0][ct] * o[0][ct] + o[1][ct] * o[1][ct];
+            }
+            if (save && q == 0 && s0 + i < a.n_pairs) {
+                float *dz = a.sv_z[side] + (size_t)(s0 + i) * H3;
+#pragma unroll
+                for (int ct = 0; ct < NT3; ++ct) { dz[ct * 16 + r] = o[0][ct]; dz[HH3 + ct * 16 + r] = o[1][ct]; }
             }
             if (a.normalize) {
 #pragma unroll
@@ -290,14 +314,15 @@ extern "C" int gs_sage3_seeds_supported(int Fu, int Fi, int H1, int H2, int H3, 
     return lds <= kLdsMax;
 }
 
-extern "C" int gs_sage3_seeds_forward(const float *feat_user, int64_t n_users, int Fu,
-                                      const float *feat_item, int64_t n_items, int Fi,
-                                      const int32_t *seeds, int64_t n_pairs, const int32_t *hop1_ids, int n0,
-                                      const float *h0_hop1, const float *h1_hop1,
-                                      const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
-                                      const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
-                                      const gs_sage_weights *l2_user, const gs_sage_weights *l2_item,
-                                      int H1, int H2, int H3, int act, int normalize, float *emb, void *stream) {
+static int seeds_forward_impl(const float *feat_user, int64_t n_users, int Fu,
+                              const float *feat_item, int64_t n_items, int Fi,
+                              const int32_t *seeds, int64_t n_pairs, const int32_t *hop1_ids, int n0,
+                              const float *h0_hop1, const float *h1_hop1,
+                              const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                              const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                              const gs_sage_weights *l2_user, const gs_sage_weights *l2_item,
+                              int H1, int H2, int H3, int act, int normalize, float *emb,
+                              const gs_sage3_seeds_saved *saved, void *stream) {
     if (n_pairs < 0) return gs::fail(GS_EINVAL, "gs_sage3_seeds_forward: n_pairs=%lld", (long long)n_pairs);
     if (n_pairs == 0) return GS_OK;
     const gs_sage_weights *ws[6] = {l0_user, l0_item, l1_user, l1_item, l2_user, l2_item};
@@ -323,6 +348,16 @@ extern "C" int gs_sage3_seeds_forward(const float *feat_user, int64_t n_users, i
             a.ws[l][t] = ws[2 * l + t]->w_self; a.wn[l][t] = ws[2 * l + t]->w_neigh; a.b[l][t] = ws[2 * l + t]->bias;
         }
     a.act = act; a.normalize = normalize; a.emb = emb;
+    if (saved) {
+        for (int t = 0; t < 2; ++t) {
+            float *const tabs[6] = {saved->x_mean0[t], saved->h0[t], saved->x_mean1[t], saved->h1[t], saved->x_mean2[t], saved->z[t]};
+            for (float *tab : tabs)
+                if (!tab || !aligned16(tab))
+                    return gs::fail(GS_EINVAL, "gs_sage3_seeds_forward_saving: a saved table is null or not 16-byte aligned (type %d)", t);
+            a.sv_x_mean0[t] = saved->x_mean0[t]; a.sv_h0[t] = saved->h0[t]; a.sv_x_mean1[t] = saved->x_mean1[t];
+            a.sv_h1[t] = saved->h1[t]; a.sv_x_mean2[t] = saved->x_mean2[t]; a.sv_z[t] = saved->z[t];
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     const int hh1 = H1 / 2, hh2 = H2 / 2;
 #define GS_X(fu, fi, a1, a2) if (Fu == fu && Fi == fi && hh1 == a1 && hh2 == a2) \
@@ -330,4 +365,30 @@ extern "C" int gs_sage3_seeds_forward(const float *feat_user, int64_t n_users, i
     GS_SAGE2_CASES(GS_X)
 #undef GS_X
     return gs::fail(GS_ELIMIT, "gs_sage3_seeds_forward: no instantiation for Fu=%d Fi=%d H1=%d H2=%d", Fu, Fi, H1, H2);
+}
+
+extern "C" int gs_sage3_seeds_forward(const float *feat_user, int64_t n_users, int Fu,
+                                      const float *feat_item, int64_t n_items, int Fi,
+                                      const int32_t *seeds, int64_t n_pairs, const int32_t *hop1_ids, int n0,
+                                      const float *h0_hop1, const float *h1_hop1,
+                                      const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                                      const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                                      const gs_sage_weights *l2_user, const gs_sage_weights *l2_item,
+                                      int H1, int H2, int H3, int act, int normalize, float *emb, void *stream) {
+    return seeds_forward_impl(feat_user, n_users, Fu, feat_item, n_items, Fi, seeds, n_pairs, hop1_ids, n0, h0_hop1, h1_hop1,
+                              l0_user, l0_item, l1_user, l1_item, l2_user, l2_item, H1, H2, H3, act, normalize, emb, nullptr, stream);
+}
+
+extern "C" int gs_sage3_seeds_forward_saving(const float *feat_user, int64_t n_users, int Fu,
+                                             const float *feat_item, int64_t n_items, int Fi,
+                                             const int32_t *seeds, int64_t n_pairs, const int32_t *hop1_ids, int n0,
+                                             const float *h0_hop1, const float *h1_hop1,
+                                             const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                                             const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                                             const gs_sage_weights *l2_user, const gs_sage_weights *l2_item,
+                                             int H1, int H2, int H3, int act, int normalize, float *emb,
+                                             const gs_sage3_seeds_saved *saved, void *stream) {
+    if (!saved) return gs::fail(GS_EINVAL, "gs_sage3_seeds_forward_saving: saved is null");
+    return seeds_forward_impl(feat_user, n_users, Fu, feat_item, n_items, Fi, seeds, n_pairs, hop1_ids, n0, h0_hop1, h1_hop1,
+                              l0_user, l0_item, l1_user, l1_item, l2_user, l2_item, H1, H2, H3, act, normalize, emb, saved, stream);
 }

@@ -686,7 +686,10 @@ class Sage3BackwardAll:
     saved: z [B, 32], h0, x_mean0, row_ids (layer-0 tables, B (1 + n0 + n0 n1) rows), h1, x_mean1 (layer-1 tables,
            B (1 + n0) rows), x_mean2 [B, 32], feat = (table, first node id) per type
     weights: {1: {type: (w_self, w_neigh)}, 2: {...}};  grads[(layer, type)] = (g_w_self, g_w_neigh, g_bias or None)
-    head: as ``Sage2BackwardAll``; fan-outs n0 (hop 1), n1 (hop 2); act: layer 2's activation"""
+    head: as ``Sage2BackwardAll``; fan-outs n0 (hop 1), n1 (hop 2); act: layer 2's activation
+    saved['hop1'] = {'h0', 'h1', 'x_mean0', 'x_mean1', 'ids'} and saved['hop2'] = {'mask' (or 'h0'), 'x_mean0', 'ids'} (each ->
+    {type: tensor}): the rows below the seeds live apart (what the subtree and seeds kernels' saving forms leave); the
+    tables above then hold the seeds' B rows only"""
 
     def __init__(self, saved, weights, grads, n0, n1, normalize, act, head=None):
         lib = load()
@@ -694,6 +697,9 @@ class Sage3BackwardAll:
         b = saved['z']['user'].shape[0]
         f = saved['x_mean0']['user'].shape[1]
         rows0, rows1 = b * (1 + n0 + n0 * n1), b * (1 + n0)
+        split = saved.get('hop1') is not None
+        if split:
+            rows0 = rows1 = b
         if not lib.gs_sage3_backward_all_supported(f, saved['x_mean0']['item'].shape[1], weights[1]['user'][0].shape[0],
                                                    2 * weights[1]['user'][0].shape[1], saved['z']['user'].shape[1], int(n0), int(n1)):
             raise _lib.GsageError("gs_sage3_backward_all does not cover this shape")
@@ -731,6 +737,29 @@ class Sage3BackwardAll:
                     if g.numel() != cnt:
                         raise ValueError("%s[%s] has %d elements, %d needed" % (name, t, g.numel(), cnt))
                     getattr(st, name)[i] = ptr(g)
+        if split:
+            h1s, h2s = _lib.Sage3BwdHop1(), _lib.Sage3BwdHop2()
+            nh1, nh2 = b * n0, b * n0 * n1
+            for i, t in enumerate(types):
+                for name, shape, dt in (('h0', (nh1, 32), torch.float32), ('h1', (nh1, 32), torch.float32),
+                                        ('x_mean0', (nh1, f), torch.float32), ('x_mean1', (nh1, 32), torch.float32),
+                                        ('ids', (nh1,), torch.int32)):
+                    x = saved['hop1'][name][t]
+                    _dev(x, dt, 'hop1[%s][%s]' % (name, t), len(shape))
+                    if tuple(x.shape) != shape:
+                        raise ValueError("hop1[%s][%s] must be %s (got %s)" % (name, t, shape, tuple(x.shape)))
+                    getattr(h1s, name)[i] = ptr(x)
+                for name, shape, dt in (('mask', (nh2,), torch.int32), ('h0', (nh2, 32), torch.float32),
+                                        ('x_mean0', (nh2, f), torch.float32), ('ids', (nh2,), torch.int32)):
+                    x = (saved['hop2'].get(name) or {}).get(t)
+                    if x is None and name in ('mask', 'h0'):
+                        continue
+                    _dev(x, dt, 'hop2[%s][%s]' % (name, t), len(shape))
+                    if tuple(x.shape) != shape:
+                        raise ValueError("hop2[%s][%s] must be %s (got %s)" % (name, t, shape, tuple(x.shape)))
+                    getattr(h2s, name)[i] = ptr(x)
+            self._hops = (h1s, h2s)
+            st.hop1, st.hop2 = ctypes.pointer(h1s), ctypes.pointer(h2s)
         self._head = head is not None
         if head is not None:
             emb, targets, kernel, bias, g_kernel, g_bias, pred, loss = head
@@ -990,7 +1019,9 @@ class Sage2Call:
         hops 2 and 3, ``emb`` (2*n_pairs*R, H2) receives relu(layer 1) at every root.  With
         'draw_hop1': int32 tensor (2*n_pairs*R) the kernel draws hop 1 too: ``run`` then takes the
         2*n_pairs seed nodes and the hop-1 ids are written to that tensor.
-        ``hop_buffers`` = (int32 tensor, int32 tensor): where the drawn ids go (instead of ``keep_ids``)."""
+        ``hop_buffers`` = (int32 tensor or None, int32 tensor or None): where the drawn ids go (instead of ``keep_ids``).
+        subtrees['saved'] (training) = {'x_mean0_hop2', 'mask_hop2', 'x_mean0_hop1', 'x_mean1_hop1'} -> {'user': tensor,
+        'item': tensor}: the tables of the rows below the first hop that ``Sage3BackwardAll`` reads (include/gsage.h)."""
         lib = load()
         _dev(indptr, torch.int64, 'indptr', 1)
         _dev(indices, torch.int32, 'indices', 1)
@@ -1047,7 +1078,22 @@ class Sage2Call:
                     raise ValueError("draw_hop1 must have %d entries" % self.n_roots)
             self._sub = _lib.Sage2Subtrees(r, int(subtrees.get('tape_len', 0)), int(subtrees.get('tape_off_hop2', 0)),
                                            int(subtrees.get('tape_off_hop3', 0)), ptr(out_h0), None, ptr(hop1_out))
-            self._sub_keep = (out_h0, hop1_out)
+            self._sub_keep = (out_h0, hop1_out, subtrees.get('saved'))
+            sv = subtrees.get('saved')
+            if sv is not None:
+                # training: the tables gs_sage3_backward_all reads below the first hop, by the node type of the rows
+                per_type = self.n_pairs * r
+                for i, t in enumerate(('user', 'item')):
+                    fo = fi if t == 'user' else fu
+                    for name, shape, dt in (('x_mean0_hop2', (per_type * n0, fo), torch.float32),
+                                            ('mask_hop2', (per_type * n0,), torch.int32),
+                                            ('x_mean0_hop1', (per_type, fo), torch.float32),
+                                            ('x_mean1_hop1', (per_type, h1), torch.float32)):
+                        buf = sv[name][t]
+                        _dev(buf, dt, 'saved[%s][%s]' % (name, t), len(shape))
+                        if tuple(buf.shape) != shape:
+                            raise ValueError("saved[%s][%s] must be %s (got %s)" % (name, t, shape, tuple(buf.shape)))
+                        getattr(self._sub, 'sv_' + name)[i] = buf.data_ptr()
             self._draw_hop1 = hop1_out is not None
         self.emb = emb if emb is not None else torch.empty((self.n_roots, h2), dtype=torch.float32, device=dev)
         _dev(self.emb, torch.float32, 'emb', 2)
@@ -1058,6 +1104,8 @@ class Sage2Call:
         if hop_buffers is not None:
             self.hop1, self.hop2 = hop_buffers
             for name, buf, n in (('hop_buffers[0]', self.hop1, self.n_roots * n0), ('hop_buffers[1]', self.hop2, self.n_roots * n0 * n1)):
+                if buf is None:                               # (either may be left out)
+                    continue
                 _dev(buf, torch.int32, name)
                 if buf.numel() != n:
                     raise ValueError("%s must have %d entries" % (name, n))
@@ -1169,7 +1217,10 @@ class Sage3SeedsCall:
     ``weights`` = {(layer, node_type): (w_self, w_neigh, bias or None)} for layers 0, 1, 2.
     """
 
-    def __init__(self, feat_user, feat_item, hop1_ids, n0, h0_hop1, h1_hop1, weights, act, normalize, n_pairs, emb):
+    def __init__(self, feat_user, feat_item, hop1_ids, n0, h0_hop1, h1_hop1, weights, act, normalize, n_pairs, emb,
+                 saved=None):
+        """``saved`` (training): {'x_mean0', 'h0', 'x_mean1', 'h1', 'x_mean2', 'z'} -> {'user': tensor, 'item': tensor}, one
+        row per seed: ``gs_sage3_seeds_forward_saving``."""
         lib = load()
         _dev(feat_user, torch.float32, 'feat_user', 2)
         _dev(feat_item, torch.float32, 'feat_item', 2)
@@ -1208,6 +1259,19 @@ class Sage3SeedsCall:
         self._head = (ptr(feat_user), nu, fu, ptr(feat_item), ni, fi)
         self._tail = (n_pairs, ptr(hop1_ids), n0, ptr(h0_hop1), ptr(h1_hop1), *[ctypes.byref(w) for w in self._w],
                       h1, h2, h3, ACT[act], int(bool(normalize)), ptr(emb))
+        self._saved = None
+        if saved is not None:
+            st = _lib.Sage3SeedsSaved()
+            for i, t in enumerate(('user', 'item')):
+                fo = fi if t == 'user' else fu
+                for name, width in (('x_mean0', fo), ('h0', h1), ('x_mean1', h1), ('h1', h2), ('x_mean2', h2), ('z', h3)):
+                    buf = saved[name][t]
+                    _dev(buf, torch.float32, 'saved[%s][%s]' % (name, t), 2)
+                    if tuple(buf.shape) != (n_pairs, width):
+                        raise ValueError("saved[%s][%s] must be %s (got %s)" % (name, t, (n_pairs, width), tuple(buf.shape)))
+                    getattr(st, name)[i] = buf.data_ptr()
+            self._saved = st
+            self._keep.append(saved)
 
     def run(self, seeds):
         if self._epoch != _storage_epoch:
@@ -1221,6 +1285,10 @@ class Sage3SeedsCall:
         _dev(seeds, torch.int32, 'seeds', 1)
         if seeds.numel() != 2 * self.n_pairs:
             raise ValueError("seeds must hold %d nodes" % (2 * self.n_pairs))
+        if self._saved is not None:
+            check(self._lib.gs_sage3_seeds_forward_saving(*self._head, ptr(seeds), *self._tail, ctypes.byref(self._saved),
+                                                          stream_handle()), 'gs_sage3_seeds_forward_saving')
+            return self.emb
         check(self._lib.gs_sage3_seeds_forward(*self._head, ptr(seeds), *self._tail, stream_handle()), 'gs_sage3_seeds_forward')
         return self.emb
 

@@ -106,6 +106,14 @@ class SageTrainEngine(SageForwardEngine):
             all(m._aggs[layer][t].activation == 'relu' for layer in (0, 1) for t in _TYPES) and
             kernels.load().gs_sage3_backward_all_supported(f['user'], f['item'], 32, 32, 32, self.fanouts[0], self.fanouts[1]))
         self._bwd3 = None
+        # ... and the forward pass below the seeds one kernel as well (the subtree kernel in its saving form: hops 2
+        # and 3 drawn where they are used, the hop-2 nodes' outputs kept as one mask word each), then one kernel over
+        # the seeds; subtree_train = False keeps the layer-by-layer forward
+        self.subtree_train = bool(
+            self.fused_backward3 and self._padded_model is None and not self.dropout and
+            kernels.sage2_subtrees_supported(f['user'], f['item'], 32, 32, self.fanouts[1], self.fanouts[2]) and
+            kernels.sage3_seeds_supported(f['user'], f['item'], 32, 32, 32, self.fanouts[0]))
+        self._sub_train = None
         # Dropout of the aggregator inputs (models.py:152,165) is drawn inside the one-kernel forward; what that
         # kernel saves are the inputs as they entered the layers, so the own rows are saved as rows (not ids) and
         # the masks carry "active and kept".
@@ -186,6 +194,8 @@ class SageTrainEngine(SageForwardEngine):
             self._padded_model.refresh()
         if self.walk_train:
             return self._forward_walks_train(seeds, walk_ids, rng_seed, replay)
+        if self.subtree_train and self.fused_backward3:
+            return self._forward_subtrees_train(seeds, walk_ids, rng_seed, replay)
         self.sample(seeds, walk_ids, rng_seed, replay)
         if self.row_ids is not None:                         # the layer-0 heads' node ids in row order, for the backward pass
             for t in _TYPES:
@@ -213,6 +223,45 @@ class SageTrainEngine(SageForwardEngine):
             else:
                 self.emb[t].copy_(self.z[t])
         return self.emb['user'], self.emb['item']
+
+    def _forward_subtrees_train(self, seeds, walk_ids, rng_seed, replay):
+        """Three hops, two launches: everything below the seeds (all three hops drawn; layers 0 and 1 per hop-1 node's
+        subtree), then the three layers at the seeds; both leave what ``_backward_three`` reads in the engine's tables
+        (the rows of the layer-by-layer route, except that the hop-1 nodes' outputs are two arrays over both node
+        types and the hop-2 nodes' are mask words)."""
+        m, b = self.model, self.batch
+        n0, n1, n2 = self.fanouts
+        if self._sub_train is None:
+            dev = self.indptr.device
+            r1, r2 = b * (1 + n0), b * (1 + n0 + n0 * n1)
+            st = {'h0': torch.empty((2 * b * n0, 32), dtype=torch.float32, device=dev),
+                  'h1': torch.empty((2 * b * n0, 32), dtype=torch.float32, device=dev),
+                  'mask': {t: torch.zeros(b * n0 * n1, dtype=torch.int32, device=dev) for t in _TYPES},
+                  'hop1': self.hops[0].reshape(-1), 'hop2': self.hops[1].reshape(-1)}
+            weights = {(l, t): (m._aggs[l][t].w_self, m._aggs[l][t].w_neigh, m._aggs[l][t].bias)
+                       for l in (0, 1, 2) for t in _TYPES}
+            below = {'x_mean0_hop2': {t: self.x_mean[0][t][r1:r2] for t in _TYPES}, 'mask_hop2': st['mask'],
+                     'x_mean0_hop1': {t: self.x_mean[0][t][b:r1] for t in _TYPES},
+                     'x_mean1_hop1': {t: self.x_mean[1][t][b:r1] for t in _TYPES}}
+            st['call'] = kernels.Sage2Call(
+                self.indptr, self.indices, self.tables['user'][0], self.tables['item'][0], [n1, n2],
+                {k: w for k, w in weights.items() if k[0] < 2}, False, b, emb=st['h1'], hop_buffers=(st['hop2'], None),
+                subtrees={'roots_per_walk': n0, 'tape_len': sum(self.sizes[1:]), 'tape_off_hop2': self.sizes[1],
+                          'tape_off_hop3': self.sizes[1] + self.sizes[2], 'out_h0': st['h0'], 'draw_hop1': st['hop1'],
+                          'saved': below})
+            at_seeds = {'x_mean0': {t: self.x_mean[0][t][:b] for t in _TYPES}, 'h0': {t: self.h[0][t][:b] for t in _TYPES},
+                        'x_mean1': {t: self.x_mean[1][t][:b] for t in _TYPES}, 'h1': {t: self.h[1][t][:b] for t in _TYPES},
+                        'x_mean2': {t: self.x_mean[2][t][:b] for t in _TYPES}, 'z': self.z}
+            st['seeds'] = kernels.Sage3SeedsCall(
+                self.tables['user'][0], self.tables['item'][0], st['hop1'], n0, st['h0'], st['h1'], weights,
+                m._aggs[2]['user'].activation, m.normalize == "l2", b, self.emb_all, saved=at_seeds)
+            self._sub_train = st
+        st = self._sub_train
+        if seeds.data_ptr() != self.seeds_buf.data_ptr():     # (the backward pass reads the seeds' own rows by these ids)
+            self.seeds_buf.copy_(seeds)
+        st['call'].run(self.seeds_buf, self.err_flag, rng_seed=rng_seed, walk_ids=walk_ids, replay=replay)
+        st['seeds'].run(self.seeds_buf)
+        return self.emb_all[:b], self.emb_all[b:]
 
     def _general_layer_train(self, layer):
         m, other = self.model, self.other
@@ -279,7 +328,8 @@ class SageTrainEngine(SageForwardEngine):
         hop-1 nodes (each with its children's rows), one reduction; every weight gradient and, with ``head``, the
         link head and the loss."""
         m = self.model
-        key = (kernels.storage_epoch(), head is not None, None if head is None else tuple(x.data_ptr() for x in head[:2] + head[3:]))
+        key = (kernels.storage_epoch(), head is not None, None if head is None else tuple(x.data_ptr() for x in head[:2] + head[3:]),
+               self.subtree_train)
         if self._bwd3 is None or self._bwd3[0] != key:
             b, n0, n1 = self.batch, self.fanouts[0], self.fanouts[1]
             rows0, rows1 = b * (1 + n0 + n0 * n1), b * (1 + n0)
@@ -287,12 +337,30 @@ class SageTrainEngine(SageForwardEngine):
                      'x_mean0': {t: self.x_mean[0][t][:rows0] for t in _TYPES},
                      'x_mean1': {t: self.x_mean[1][t][:rows1] for t in _TYPES},
                      'x_mean2': {t: self.x_mean[2][t][:b] for t in _TYPES}}
+            emb = self.emb
+            if self.subtree_train:
+                # the rows below the seeds where the subtree kernel left them: the hop-1 nodes' outputs and the ids in
+                # arrays over both node types (those below the user seeds -- items -- first), the rest in the tables
+                st = self._sub_train
+                h1n, h2n = b * n0, b * n0 * n1
+                part = lambda x, t, n: x[:n] if t == 'item' else x[n:]          # hop-1 nodes of type t
+                part2 = lambda x, t, n: x[:n] if t == 'user' else x[n:]         # hop-2 nodes of type t (below item-typed hop-1 nodes first)
+                for name in ('h0', 'h1', 'x_mean0', 'x_mean1'):
+                    saved[name] = {t: saved[name][t][:b] for t in _TYPES}
+                saved['row_ids'] = {'user': self.seeds_buf[:b], 'item': self.seeds_buf[b:]}
+                saved['hop1'] = {'h0': {t: part(st['h0'], t, h1n) for t in _TYPES}, 'h1': {t: part(st['h1'], t, h1n) for t in _TYPES},
+                                 'x_mean0': {t: self.x_mean[0][t][b:rows1] for t in _TYPES},
+                                 'x_mean1': {t: self.x_mean[1][t][b:rows1] for t in _TYPES},
+                                 'ids': {t: part(st['hop1'], t, h1n) for t in _TYPES}}
+                saved['hop2'] = {'mask': st['mask'], 'x_mean0': {t: self.x_mean[0][t][rows1:rows0] for t in _TYPES},
+                                 'ids': {t: part2(st['hop2'], t, h2n) for t in _TYPES}}
+                emb = {'user': self.emb_all[:b], 'item': self.emb_all[b:]}
             weights = {layer: {t: (m._aggs[layer][t].w_self, m._aggs[layer][t].w_neigh) for t in _TYPES} for layer in (1, 2)}
             grads = {(layer, t): self._grads_of(m._aggs[layer][t]) for layer in (0, 1, 2) for t in _TYPES}
             hd = None
             if head is not None:
                 head_kernel, head_bias, targets, g_kernel, g_bias, pred, loss = head
-                hd = ({'user': self.emb['user'], 'item': self.emb['item']}, targets, head_kernel, head_bias, g_kernel, g_bias, pred, loss)
+                hd = ({'user': emb['user'], 'item': emb['item']}, targets, head_kernel, head_bias, g_kernel, g_bias, pred, loss)
             self._bwd3 = (key, kernels.Sage3BackwardAll(saved, weights, grads, n0, n1, m.normalize == "l2",
                                                         m._aggs[2]['user'].activation, head=hd))
         if head is not None:

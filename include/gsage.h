@@ -501,6 +501,16 @@ int gs_sage2_forward(const int64_t *indptr, const int32_t *indices, int64_t n_no
  * What remains for the caller are the seed nodes themselves: layer 0 and layer 1 at the seeds (neighbors: the
  * hop-1 nodes' feature rows / out_h0 rows) and layer 2 (neighbors: h1_out rows): gs_sage3_seeds_forward, or
  * gs_sage_fused_fwd per layer.
+ * Training (the sv_ tables, all or none; H1 = 32): what gs_sage3_backward_all reads below the first hop is
+ * written on the way, indexed by the node type t of the rows (o = the other type), i = the index of a hop-1
+ * node among those of its type (the item-typed ones hang below the user seeds):
+ *   sv_x_mean0_hop2[t] [n_pairs*roots_per_walk*n1, F_o]  the layer-0 neighbor mean of hop-2 node k below hop-1
+ *                      node i (of type o), row i*n1 + k
+ *   sv_mask_hop2[t]    [n_pairs*roots_per_walk*n1]       the same rows: bit c says layer-0 output column c > 0
+ *                      (the outputs themselves are needed by nothing: layer 1 reads their mean)
+ *   sv_x_mean0_hop1[t] [n_pairs*roots_per_walk, F_o], sv_x_mean1_hop1[t] [.., H1]   the layer-0 / layer-1
+ *                      neighbor means of hop-1 node i
+ * together with out_h0, h1_out (the hop-1 nodes' outputs), out_hop2 (the hop-2 ids) and the hop-1 ids.
  * Shapes: gs_sage2_subtrees_supported(Fu, Fi, H1, H2, n1, n2) != 0 (those of gs_sage2_supported whose eight
  * subtrees' ids fit a wavefront's share of LDS); others get GS_ELIMIT.
  */
@@ -510,6 +520,10 @@ typedef struct gs_sage2_subtrees {
     float *out_h0;
     const int32_t *seeds;
     int32_t *out_hop1;
+    float *sv_x_mean0_hop2[2];
+    uint32_t *sv_mask_hop2[2];
+    float *sv_x_mean0_hop1[2];
+    float *sv_x_mean1_hop1[2];
 } gs_sage2_subtrees;
 
 int gs_sage2_subtrees_supported(int Fu, int Fi, int H1, int H2, int n1, int n2);
@@ -546,6 +560,26 @@ int gs_sage3_seeds_forward(const float *feat_user, int64_t n_users, int Fu,
                            const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
                            const gs_sage_weights *l2_user, const gs_sage_weights *l2_item,
                            int H1, int H2, int H3, int act, int normalize, float *emb, void *stream);
+
+/*
+ * The same, leaving what the backward pass reads at the seeds (gs_sage3_backward_all): per seed type t, one row per
+ * seed -- x_mean0 [n_pairs, F_o], x_mean1 [n_pairs, H1], x_mean2 [n_pairs, H2] the neighbor means the three layers
+ * read; h0 [n_pairs, H1], h1 [n_pairs, H2] the outputs of layers 0 and 1; z [n_pairs, H3] layer 2's output after its
+ * activation, before the normalisation.  All twelve tables are required, 16-byte aligned.
+ */
+typedef struct gs_sage3_seeds_saved {
+    float *x_mean0[2], *h0[2], *x_mean1[2], *h1[2], *x_mean2[2], *z[2];
+} gs_sage3_seeds_saved;
+
+int gs_sage3_seeds_forward_saving(const float *feat_user, int64_t n_users, int Fu,
+                                  const float *feat_item, int64_t n_items, int Fi,
+                                  const int32_t *seeds, int64_t n_pairs, const int32_t *hop1_ids, int n0,
+                                  const float *h0_hop1, const float *h1_hop1,
+                                  const gs_sage_weights *l0_user, const gs_sage_weights *l0_item,
+                                  const gs_sage_weights *l1_user, const gs_sage_weights *l1_item,
+                                  const gs_sage_weights *l2_user, const gs_sage_weights *l2_item,
+                                  int H1, int H2, int H3, int act, int normalize, float *emb,
+                                  const gs_sage3_seeds_saved *saved, void *stream);
 
 /*
  * The layer-0 relu masks for gs_sage2_backward_tail / gs_sage2_backward_tail_head (their nullable l0_mask argument), in which case g_h1 leaves as the
@@ -688,10 +722,27 @@ typedef struct gs_sage2_bwd_all {
  *   h0 / h1: the layers' outputs after relu;  x_mean*: the neighbor means the layers read;  row_ids: the node id of
  *   every layer-0 row (own rows are read from feat, feat_rows rows whose first holds node feat_off; ids outside count
  *   as rows of zeros)
+ * The rows below the seeds may live apart from the seeds' (what gs_sage2_forward_subtrees and
+ * gs_sage3_seeds_forward_saving leave): hop1 != NULL gives the hop-1 rows of every table -- h0, h1, x_mean1 [B n0, 32],
+ * x_mean0 [B n0, F], ids [B n0], all required -- and hop2 != NULL the hop-2 rows -- x_mean0 [B n0 n1, F], ids, and
+ * h0 [.., 32] or, instead, mask [..] words whose bit c says h0[row, c] > 0; the whole tables then need only the rows
+ * above.
  * act is layer 2's activation; weights w1_*, w2_* [32, 16]; gradients g_w0_* [F, 16], g_w1_*, g_w2_* [32, 16], g_b*
  * [32] (nullable).  Shapes: gs_sage3_backward_all_supported() != 0 (F = 32 or 64 for both node types, 32 units in
  * all three layers, n1 <= 32) and n_pairs (1 + n0 + n0 n1) F < 2^31; else GS_ELIMIT.
  */
+typedef struct gs_sage3_bwd_hop1 {
+    const float *h0[2], *h1[2], *x_mean0[2], *x_mean1[2];
+    const int32_t *ids[2];
+} gs_sage3_bwd_hop1;
+
+typedef struct gs_sage3_bwd_hop2 {
+    const float *h0[2];         /* or NULL with mask */
+    const uint32_t *mask[2];
+    const float *x_mean0[2];
+    const int32_t *ids[2];
+} gs_sage3_bwd_hop2;
+
 typedef struct gs_sage3_bwd {
     const float *z[2], *emb[2], *g_emb[2];
     const float *targets, *head_kernel, *head_bias;
@@ -705,7 +756,10 @@ typedef struct gs_sage3_bwd {
     float *g_w1_self[2], *g_w1_neigh[2], *g_b1[2];
     float *g_w2_self[2], *g_w2_neigh[2], *g_b2[2];
     float *g_head_kernel, *g_head_bias, *loss;
+    const gs_sage3_bwd_hop1 *hop1;          /* nullable */
+    const gs_sage3_bwd_hop2 *hop2;          /* nullable: required with hop1 */
 } gs_sage3_bwd;
+
 
 int gs_sage3_backward_all_supported(int Fu, int Fi, int H1, int H2, int H3, int n0, int n1);
 size_t gs_sage3_backward_all_workspace(int64_t n_pairs, int n0, int F);

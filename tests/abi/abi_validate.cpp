@@ -261,6 +261,20 @@ int main() {
         REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, nullptr, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
         sub.seeds = i32;
         REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, nullptr, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        // the saving form: all eight tables or none, aligned, 32 units in layer 0
+        sub.seeds = nullptr;
+        sub.sv_x_mean0_hop2[0] = f;
+        REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        for (int t = 0; t < 2; ++t) {
+            sub.sv_x_mean0_hop2[t] = sub.sv_x_mean0_hop1[t] = sub.sv_x_mean1_hop1[t] = f;
+            sub.sv_mask_hop2[t] = reinterpret_cast<uint32_t *>(i32);
+        }
+        REFUSED(GS_ELIMIT, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 64, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        sub.sv_x_mean1_hop1[1] = odd;
+        REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
+        sub.sv_x_mean1_hop1[1] = f;
+        sub.sv_mask_hop2[0] = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(i32) + 4);       // 8-byte alignment
+        REFUSED(GS_EINVAL, gs_sage2_forward_subtrees(i64, i32, 100, f, 60, 64, f, 40, 64, i32, 8, 10, 5, 1, 0, nullptr, nullptr, &w, &w, &w, &w, 32, 32, f, nullptr, nullptr, &sub, i32, nullptr));
     }
 
     EXPECT(gs_sage2_subtrees_supported(64, 64, 32, 32, 10, 5) == 1);
@@ -282,6 +296,17 @@ int main() {
     REFUSED(GS_EINVAL, gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, 7, 1, f, nullptr));
     REFUSED(GS_EINVAL, gs_sage3_seeds_forward(f, 0, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, nullptr));
     REFUSED(GS_ELIMIT, gs_sage3_seeds_forward(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 48, GS_ACT_LINEAR, 1, f, nullptr));
+    {
+        gs_sage3_seeds_saved ss{};
+        REFUSED(GS_EINVAL, gs_sage3_seeds_forward_saving(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, nullptr, nullptr));
+        REFUSED(GS_EINVAL, gs_sage3_seeds_forward_saving(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, &ss, nullptr));
+        for (int t = 0; t < 2; ++t) ss.x_mean0[t] = ss.h0[t] = ss.x_mean1[t] = ss.h1[t] = ss.x_mean2[t] = ss.z[t] = f;
+        ACCEPTED(gs_sage3_seeds_forward_saving(f, 60, 64, f, 40, 64, i32, 0, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, &ss, nullptr));
+        ss.h1[1] = odd;
+        REFUSED(GS_EINVAL, gs_sage3_seeds_forward_saving(f, 60, 64, f, 40, 64, i32, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, &ss, nullptr));
+        ss.h1[1] = f;
+        REFUSED(GS_EINVAL, gs_sage3_seeds_forward_saving(f, 60, 64, f, 40, 64, nullptr, 8, i32, 25, f, f, &w, &w, &w, &w, &w, &w, 32, 32, 32, GS_ACT_LINEAR, 1, f, &ss, nullptr));
+    }
 
     // ---- top of the backward pass ----
     ACCEPTED(gs_sage2_backward_tail(f, f, f, f, 0, 25, 32, 32, 1, GS_ACT_LINEAR, f, f, f, f, f, f, f, f, nullptr, nullptr));
@@ -400,6 +425,20 @@ int main() {
         p.g_w2_self[0] = nullptr;
         p.x_mean0[1] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(f) + 4);                        // not 16-byte aligned
         REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));
+        p.x_mean0[1] = f;
+        // the rows below the seeds apart: hop1 needs hop2, every table of either, hop2 its outputs as rows or as masks
+        gs_sage3_bwd_hop1 h1{};
+        gs_sage3_bwd_hop2 h2{};
+        p.hop1 = &h1;
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));   // empty hop1
+        for (int t = 0; t < 2; ++t) { h1.h0[t] = h1.h1[t] = h1.x_mean0[t] = h1.x_mean1[t] = f; h1.ids[t] = i32; }
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));   // no hop2
+        p.hop2 = &h2;
+        for (int t = 0; t < 2; ++t) { h2.x_mean0[t] = f; h2.ids[t] = i32; }
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));   // neither h0 nor mask
+        h2.mask[0] = h2.mask[1] = reinterpret_cast<const uint32_t *>(i32);
+        h2.x_mean0[0] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(f) + 4);
+        REFUSED(GS_EINVAL, gs_sage3_backward_all(&p, 8, 25, 10, 64, 1, GS_ACT_LINEAR, arena, b3, nullptr, nullptr));   // alignment
     }
 
     // ---- link head, optimizer, staging ----

@@ -107,3 +107,45 @@ def test_three_hop_backward_equals_float64_sums(b, n0, n1, f, normalize, act):
     for key in grads:
         for x, y in zip(grads[key], first[key]):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('b,n0,n1,f,with_mask', [(16, 25, 10, 64, True), (9, 7, 17, 32, False), (70, 3, 13, 64, True)])
+def test_rows_below_the_seeds_given_apart_give_the_same_bits(b, n0, n1, f, with_mask):
+    """The hop-1 and hop-2 rows as tables of their own (hop-2 outputs as one mask word per row, or as rows) against
+    the same rows inside the whole tables."""
+    dev = torch.device('cuda', 0)
+    t = _tables(b, n0, n1, f, 5 + b)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    weights = {1: {k: (dv(t['w1'][k][0]), dv(t['w1'][k][1])) for k in TYPES}, 2: {k: (dv(t['w2'][k][0]), dv(t['w2'][k][1])) for k in TYPES}}
+    g_emb = {k: dv(t['g_emb'][k]) for k in TYPES}
+
+    def run(saved):
+        grads = {}
+        for layer, kdim in ((0, f), (1, 32), (2, 32)):
+            for k in TYPES:
+                grads[(layer, k)] = (torch.full((kdim, 16), 7.0, device=dev), torch.full((kdim, 16), 7.0, device=dev),
+                                     torch.full((32,), 7.0, device=dev))
+        kernels.Sage3BackwardAll(saved, weights, grads, n0, n1, True, 'linear').run(g_emb=g_emb)
+        torch.cuda.synchronize()
+        return grads
+
+    whole = {name: {k: dv(t[name][k]) for k in TYPES} for name in ('z', 'h0', 'h1', 'x_mean0', 'x_mean1', 'x_mean2', 'row_ids')}
+    whole['feat'] = {k: (dv(t['table'][k]), t['first']) for k in TYPES}
+    want = run(whole)
+
+    h1_end = b * (1 + n0)
+    apart = {name: {k: dv(t[name][k][:b]) for k in TYPES} for name in ('z', 'h0', 'h1', 'x_mean0', 'x_mean1', 'x_mean2', 'row_ids')}
+    apart['feat'] = whole['feat']
+    apart['hop1'] = {name: {k: dv(t[src][k][b:h1_end]) for k in TYPES}
+                     for name, src in (('h0', 'h0'), ('h1', 'h1'), ('x_mean0', 'x_mean0'), ('x_mean1', 'x_mean1'), ('ids', 'row_ids'))}
+    apart['hop2'] = {'x_mean0': {k: dv(t['x_mean0'][k][h1_end:]) for k in TYPES}, 'ids': {k: dv(t['row_ids'][k][h1_end:]) for k in TYPES}}
+    if with_mask:
+        bits = {k: ((t['h0'][k][h1_end:] > 0).astype(np.uint32) << np.arange(32, dtype=np.uint32)).sum(1, dtype=np.uint64).astype(np.uint32)
+                for k in TYPES}
+        apart['hop2']['mask'] = {k: dv(bits[k].view(np.int32)) for k in TYPES}
+    else:
+        apart['hop2']['h0'] = {k: dv(t['h0'][k][h1_end:]) for k in TYPES}
+    got = run(apart)
+    for key in want:
+        for x, y in zip(got[key], want[key]):
+            assert torch.equal(x, y), key

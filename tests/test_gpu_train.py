@@ -653,33 +653,37 @@ def test_optimizer_step_inside_the_backward_reduction_equals_the_separate_launch
     assert float((p0 - out[0][1]).abs().max()) == 0 and l0[2] < l0[0] + 1e-3
 
 
-@pytest.mark.parametrize('ns,f', [([5, 3, 2], 64), ([3, 10, 4], 32)])
-def test_three_hop_backward_in_two_kernels_equals_the_layer_by_layer_launches(cuda, ns, f):
-    """Three hops, 32 units per layer: a step with the backward pass as a kernel over the seeds, a kernel over the
-    hop-1 nodes and one reduction, against the layer-by-layer launches on the same tables: same loss, same gradients
-    up to the order of the sums; the two-kernel form repeats its bits, and with Adam inside its reduction the
+@pytest.mark.parametrize('ns,f,b', [([5, 3, 2], 64, 48), ([3, 10, 4], 32, 48), ([3, 2, 2], 64, 45)])     # (45 * 3 hop-1 nodes: a last group of 7)
+def test_three_hop_backward_in_two_kernels_equals_the_layer_by_layer_launches(cuda, ns, f, b):
+    """Three hops, 32 units per layer: a step with the forward pass as a kernel below the seeds and one over the seeds, the
+    backward pass as a kernel over the seeds, a kernel over the hop-1 nodes and one reduction, against the layer-by-layer
+    launches of either pass: same loss, same gradients up to the order of the sums; the two-kernel form repeats its bits, and with Adam inside its reduction the
     weights equal those of the separate update."""
     from graphsage_amd.train import LinkHead
     g, links, targets = _toy(5, fu=f, fi=f)
-    b, sizes = 48, [32, 32, 32]
+    sizes = [32, 32, 32]
     out = []
-    for fused, fuse_update in ((True, True), (False, True), (True, False), (True, True)):
+    for fused, fuse_update, subtree in ((True, True, True), (False, True, True), (True, False, True), (True, True, True),
+                                        (True, True, False)):
         gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
         model = ga.GraphSAGE(sizes, gen, seed=11)
         model.build()
         tr = Trainer(model, head=LinkHead(sizes[-1], cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
-        assert tr.engine.fused_backward3 and not tr.engine.tail_kernel
+        assert tr.engine.fused_backward3 and tr.engine.subtree_train and not tr.engine.tail_kernel
         tr.engine.fused_backward3 = fused
+        tr.engine.subtree_train = subtree             # (False: the layer-by-layer forward pass under the two backward kernels)
         tr.fuse_update = fuse_update
         lk = np.asarray(links[:b])
         seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
         loss, pred = tr.step_device(seeds, torch.from_numpy(targets[:b]).to(cuda),
                                     torch.arange(2 * b, dtype=torch.int64, device=cuda), rng_seed=9)
         out.append((float(loss), tr.bucket.flat.clone(), tr.opt.p_flat.clone(), pred.clone()))
-    assert abs(out[0][0] - out[1][0]) <= 1e-6 * max(1.0, abs(out[1][0]))
-    assert float((out[0][3] - out[1][3]).abs().max()) < 1e-6
     scale = float(out[1][1].abs().max())
-    assert scale > 0 and float((out[0][1] - out[1][1]).abs().max()) <= 3e-6 * scale
+    assert scale > 0
+    for other in (1, 4):                              # against the layered forward, under either backward pass
+        assert abs(out[0][0] - out[other][0]) <= 1e-6 * max(1.0, abs(out[other][0]))
+        assert float((out[0][3] - out[other][3]).abs().max()) < 1e-6
+        assert float((out[0][1] - out[other][1]).abs().max()) <= 3e-6 * scale
     assert torch.equal(out[0][1], out[3][1]) and torch.equal(out[0][2], out[3][2]) and out[0][0] == out[3][0]
     assert torch.equal(out[0][1], out[2][1]) and torch.equal(out[0][2], out[2][2])      # Adam inside / after the reduction
 
