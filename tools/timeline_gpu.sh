@@ -14,7 +14,7 @@ rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # the launch that ends a step (the update: a kernel of its own, or the reduction of the one-kernel backward pass);
 # the last one = end of the last step; walk back to the one before
-last='sage2_bwd_reduce_kernel' if any('sage2_bwd_reduce_kernel' in r['Kernel_Name'] for r in rows) and not any('adam_kernel' in r['Kernel_Name'] for r in rows[-40:]) else 'adam_kernel'
+last='bwd_reduce_kernel' if any('bwd_reduce_kernel' in r['Kernel_Name'] for r in rows) and not any('adam_kernel' in r['Kernel_Name'] for r in rows[-40:]) else 'adam_kernel'
 idx=[i for i,r in enumerate(rows) if last in r['Kernel_Name']]
 a,b=idx[-2],idx[-1]
 t0=int(rows[a]['End_Timestamp'])
