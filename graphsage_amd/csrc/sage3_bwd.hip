@@ -320,7 +320,7 @@ void sage3_bwd_seeds_kernel(const Bwd3Args a) {
 
 // ---- subtrees ---------------------------------------------------------------------------------------------
 // TT: the type of the seed the subtrees hang below (= the type of their hop-2 children); their roots are of type 1 - TT.
-template <int F, int U, int TT>
+template <int F, int U, bool MASK, int TT>
 __device__ __forceinline__ void subtrees_of_type(const Bwd3Args &a, Sums3<F> &sums, const float *wt, float *line, float *wsum,
                                                  int lane, long long i_first, long long i_step) {
     constexpr int V = F / 16, O = 1 - TT;
@@ -331,7 +331,7 @@ __device__ __forceinline__ void subtrees_of_type(const Bwd3Args &a, Sums3<F> &su
     const float *a_row = a.a_row[TT], *b_row = a.b_row[TT];
     const float *h1 = a.h1_hop1[O], *h0r = a.h0_hop1[O], *m1 = a.x_mean1_hop1[O];
     const float *h0c = a.h0_hop2[TT], *xn_c = a.x_mean0_hop2[TT], *feat_c = a.feat[TT];
-    const uint32_t *mk_c = a.mask_hop2[TT];
+    const uint32_t *mk_c = a.mask_hop2[TT];                      // (MASK: instead of h0c)
     const float *xn_r = a.x_mean0_hop1[O], *feat_r = a.feat[O];
     const int32_t *ids_c = a.ids_hop2[TT], *ids_r = a.ids_hop1[O];
     const long long off_c = a.feat_off[TT], rows_c = a.feat_rows[TT], off_r = a.feat_off[O], rows_r = a.feat_rows[O];
@@ -342,7 +342,7 @@ __device__ __forceinline__ void subtrees_of_type(const Bwd3Args &a, Sums3<F> &su
     sums.clear_layer0(TT);
 
     struct Sub { float av, bv, h1v, h0v, m1v; int32_t idv; uint32_t mwv; };
-    auto load_sub = [&](Sub &s, long long i) {
+    auto load_sub = [&](Sub &s, long long i) __attribute__((always_inline)) {
         const long long p = i / n0;
         s.av = a_row[p * kH + k];
         s.bv = b_row[p * kH + k];
@@ -350,71 +350,110 @@ __device__ __forceinline__ void subtrees_of_type(const Bwd3Args &a, Sums3<F> &su
         s.h0v = h0r[i * kH + k];
         s.m1v = m1[i * kH + k];
         s.idv = ids_c[i * n1 + min(lane, n1 - 1)];               // lane j: child j (n1 <= 32)
-        s.mwv = mk_c ? mk_c[i * n1 + min(lane, n1 - 1)] : 0u;
+        s.mwv = MASK ? mk_c[i * n1 + min(lane, n1 - 1)] : 0u;
     };
-    Sub nxt;
-    if (i_first < n_sub) load_sub(nxt, i_first);
-    __syncthreads();                                              // weights staged, LDS sums zeroed (every wave passes here once)
+    // The rows of 4 * U children (slots g0 * 4 .. ; lane quarter q takes slot 4 * g + q): own row by id, saved
+    // neighbor mean, and the relu masks of columns r and 16 + r (as 1 / 0, or the layer-0 outputs themselves).
+    struct Rows { Row<V> xs[U], xn[U]; float ml[U], mh[U]; uint32_t okbits; };
+    auto issue = [&](Rows &R, const Sub &s, long long i, int g0) __attribute__((always_inline)) {
+        R.okbits = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int g = g0 + u;
+            const int j = min(4 * g + q, n1 - 1);                 // (a slot past n1 reads child n1-1 in place, weight 0)
+            const unsigned row = (unsigned)(i * n1) + j;          // (rows * F < 2^31: checked by the host)
+            long long own = (long long)__shfl(s.idv, j, 64) - off_c;
+            const bool ok = (unsigned long long)own < (unsigned long long)rows_c;
+            if (!ok) own = 0;
+            R.okbits |= (ok ? 1u : 0u) << u;
+            R.xs[u].load(feat_c + own * F + V * r);
+            R.xn[u].load(xn_c + (row * F + V * r));
+            if constexpr (MASK) {                                 // the mask word of the row, from the lane that read it
+                const uint32_t mw = (uint32_t)__shfl((int)s.mwv, j, 64);
+                R.ml[u] = (mw >> r) & 1u ? 1.f : 0.f;
+                R.mh[u] = (mw >> (16 + r)) & 1u ? 1.f : 0.f;
+            } else {
+                R.ml[u] = h0c[row * kH + r];
+                R.mh[u] = h0c[row * kH + 16 + r];
+            }
+        }
+    };
     const float inv_n1 = 1.f / (float)n1;
-    for (long long i = i_first; i < n_sub; i += i_step) {
-        const Sub s = nxt;
-        load_sub(nxt, i + i_step < n_sub ? i + i_step : i);
-        float v_lo = 0.f, v_hi = 0.f;
-        for (int g0 = 0; g0 < NS; g0 += U) {
-            Row<V> xs[U], xn[U];
-            float ml[U], mh[U];                                   // the children's layer-0 outputs, columns r and 16 + r (their relu masks)
-            uint32_t okbits = 0;
+    // Layer 1 at the root of subtree i; leaves the children's layer-0 gradient row (before their masks) in v_lo / v_hi
+    // (columns r and 16 + r) and the root's own layer-0 gradient row in root_g.
+    auto root_layer1 = [&](const Sub &s, long long i, float &v_lo, float &v_hi) __attribute__((always_inline)) {
+        const float gp1 = s.h1v > 0.f ? s.av : 0.f;               // through layer 1's relu at the root
+        if (lane < kH) g_s[lane] = gp1;
+        wave_lds_fence();
+        float ds, dn;
+        layer_back(g_s, w1s, w1n, wsum, half ? s.m1v : s.h0v, lane, ds, dn);
+        sums.b1[O] += lane < kH ? gp1 : 0.f;
+        if (lane < kH) {
+            v_s[lane] = dn * inv_n1;
+            root_g[i * kH + lane] = s.h0v > 0.f ? s.bv + ds : 0.f;       // the root's own, through its relu
+        }
+        wave_lds_fence();
+        v_lo = v_s[r]; v_hi = v_s[16 + r];
+        wave_lds_fence();                                         // the lines are rewritten by the next subtree
+    };
+    auto process = [&](const Rows &R, int g0, float v_lo, float v_hi) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int g = g0 + u;
-                const int j = min(4 * g + q, n1 - 1);             // (a slot past n1 reads child n1-1 in place, weight 0)
-                const unsigned row = (unsigned)(i * n1) + j;      // (rows * F < 2^31: checked by the host)
-                long long own = (long long)__shfl(s.idv, j, 64) - off_c;
-                const bool ok = (unsigned long long)own < (unsigned long long)rows_c;
-                if (!ok) own = 0;
-                okbits |= (ok ? 1u : 0u) << u;
-                xs[u].load(feat_c + own * F + V * r);
-                xn[u].load(xn_c + (row * F + V * r));
-                if (mk_c) {                                       // (uniform) the mask word of the row, from the lane that read it
-                    const uint32_t mw = (uint32_t)__shfl((int)s.mwv, j, 64);
-                    ml[u] = (mw >> r) & 1u ? 1.f : 0.f;
-                    mh[u] = (mw >> (16 + r)) & 1u ? 1.f : 0.f;
-                } else {
-                    ml[u] = h0c[row * kH + r];
-                    mh[u] = h0c[row * kH + 16 + r];
-                }
+        for (int u = 0; u < U; ++u) {
+            const int g = g0 + u;
+            if (g >= NS) break;
+            const bool ok = (R.okbits >> u) & 1u;
+            const bool live = 4 * g + q < n1;
+            const float bs = (live && R.ml[u] > 0.f) ? v_lo : 0.f;
+            const float bn = (live && R.mh[u] > 0.f) ? v_hi : 0.f;
+#pragma unroll
+            for (int tt = 0; tt < V; ++tt) {
+                sums.w0s[TT][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? R.xs[u].v[tt] : 0.f, bs, sums.w0s[TT][tt], 0, 0, 0);
+                sums.w0n[TT][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(R.xn[u].v[tt], bn, sums.w0n[TT][tt], 0, 0, 0);
             }
-            if (g0 == 0) {
-                // ---- layer 1 at the root, while its children's rows arrive ----
-                const float gp1 = s.h1v > 0.f ? s.av : 0.f;       // through layer 1's relu at the root
-                if (lane < kH) g_s[lane] = gp1;
-                wave_lds_fence();
-                float ds, dn;
-                layer_back(g_s, w1s, w1n, wsum, half ? s.m1v : s.h0v, lane, ds, dn);
-                sums.b1[O] += lane < kH ? gp1 : 0.f;
-                if (lane < kH) {
-                    v_s[lane] = dn * inv_n1;                      // the children's layer-0 gradient row, before their masks
-                    root_g[i * kH + lane] = s.h0v > 0.f ? s.bv + ds : 0.f;       // the root's own, through its relu
-                }
-                wave_lds_fence();
-                v_lo = v_s[r]; v_hi = v_s[16 + r];
-                wave_lds_fence();                                 // the lines are rewritten by the next subtree
+            sums.b0s[TT] += bs;
+            sums.b0n[TT] += bn;
+        }
+    };
+    constexpr bool PIPE = U <= 4;                                 // two sets of rows fit the registers
+    if constexpr (PIPE) {
+        // The first 4 * U children's rows of the NEXT subtree are requested before this subtree's are used, so a
+        // wavefront always has a subtree's rows in flight; what a request needs (ids, mask words) is read two ahead.
+        const bool any = i_first < n_sub;
+        auto at = [&](long long i) { return i < n_sub ? i : (any ? i_first : 0); };      // (past the end: a valid subtree again, unused)
+        Sub cur, nxt;
+        load_sub(cur, at(i_first));
+        load_sub(nxt, at(i_first + i_step));
+        __syncthreads();                                          // weights staged, LDS sums zeroed (every wave passes here once)
+        Rows R;
+        issue(R, cur, at(i_first), 0);
+        for (long long i = i_first; i < n_sub; i += i_step) {
+            Sub nxt2;
+            load_sub(nxt2, at(i + 2 * i_step));
+            Rows Rn;
+            issue(Rn, nxt, at(i + i_step), 0);
+            float v_lo, v_hi;
+            root_layer1(cur, i, v_lo, v_hi);
+            process(R, 0, v_lo, v_hi);
+            for (int g0 = U; g0 < NS; g0 += U) {                  // (more than 4 * U children)
+                Rows Rx;
+                issue(Rx, cur, i, g0);
+                process(Rx, g0, v_lo, v_hi);
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int g = g0 + u;
-                if (g >= NS) break;
-                const bool ok = (okbits >> u) & 1u;
-                const bool live = 4 * g + q < n1;
-                const float bs = (live && ml[u] > 0.f) ? v_lo : 0.f;
-                const float bn = (live && mh[u] > 0.f) ? v_hi : 0.f;
-#pragma unroll
-                for (int tt = 0; tt < V; ++tt) {
-                    sums.w0s[TT][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? xs[u].v[tt] : 0.f, bs, sums.w0s[TT][tt], 0, 0, 0);
-                    sums.w0n[TT][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[u].v[tt], bn, sums.w0n[TT][tt], 0, 0, 0);
-                }
-                sums.b0s[TT] += bs;
-                sums.b0n[TT] += bn;
+            cur = nxt; nxt = nxt2; R = Rn;
+        }
+    } else {
+        Sub nxt;
+        if (i_first < n_sub) load_sub(nxt, i_first);
+        __syncthreads();                                          // weights staged, LDS sums zeroed (every wave passes here once)
+        for (long long i = i_first; i < n_sub; i += i_step) {
+            const Sub s = nxt;
+            load_sub(nxt, i + i_step < n_sub ? i + i_step : i);
+            float v_lo = 0.f, v_hi = 0.f;
+            for (int g0 = 0; g0 < NS; g0 += U) {
+                Rows R;
+                issue(R, s, i, g0);
+                if (g0 == 0) root_layer1(s, i, v_lo, v_hi);       // while the first rows arrive
+                process(R, g0, v_lo, v_hi);
             }
         }
     }
@@ -444,7 +483,7 @@ __device__ __forceinline__ void subtrees_of_type(const Bwd3Args &a, Sums3<F> &su
     }
 }
 
-template <int F, int U>
+template <int F, int U, bool MASK>
 __global__ __launch_bounds__(kThreads)
 void sage3_bwd_subtrees_kernel(const Bwd3Args a, int slab_row0) {
     extern __shared__ float smem[];
@@ -466,8 +505,8 @@ void sage3_bwd_subtrees_kernel(const Bwd3Args a, int slab_row0) {
     // wave's parity -- write_slab reads wave w's sums as type w & 1, so the waves swap places there (see below).
     const long long gw = (long long)blockIdx.x * kWaves + wave, i_step = (long long)gridDim.x * (kWaves / 2);
     float *wsum = wsum_all + (wave ^ 1) * (2 * S::kW);           // (layer-1 part of the neighbor wave's place)
-    if (gw & 1) subtrees_of_type<F, U, 1>(a, sums, wt, line, wsum, lane, gw >> 1, i_step);
-    else subtrees_of_type<F, U, 0>(a, sums, wt, line, wsum, lane, gw >> 1, i_step);
+    if (gw & 1) subtrees_of_type<F, U, MASK, 1>(a, sums, wt, line, wsum, lane, gw >> 1, i_step);
+    else subtrees_of_type<F, U, MASK, 0>(a, sums, wt, line, wsum, lane, gw >> 1, i_step);
     write_slab<F>(sums, regions, wsum_all, a.slab + (size_t)(slab_row0 + blockIdx.x) * S::size(), wave, lane);
 }
 
@@ -519,6 +558,8 @@ extern "C" int gs_sage3_backward_all(const gs_sage3_bwd *p, int64_t n_pairs, int
             return gs::fail(GS_EINVAL, "%s: hop1 has a null table (type %d)", who, t);
         if (h2p && (!h2p->x_mean0[t] || !h2p->ids[t] || (!h2p->h0[t] && !h2p->mask[t])))
             return gs::fail(GS_EINVAL, "%s: hop2 needs x_mean0, ids and h0 or mask (type %d)", who, t);
+        if (h2p && !h2p->mask[0] != !h2p->mask[1])
+            return gs::fail(GS_EINVAL, "%s: hop2 mask words are given for both node types or for none", who);
         a.z[t] = p->z[t]; a.emb[t] = p->emb[t]; a.g_emb[t] = p->g_emb[t];
         a.w2_self[t] = p->w2_self[t]; a.w2_neigh[t] = p->w2_neigh[t]; a.w1_self[t] = p->w1_self[t]; a.w1_neigh[t] = p->w1_neigh[t];
         a.x_mean2[t] = p->x_mean2[t];
@@ -599,24 +640,35 @@ extern "C" int gs_sage3_backward_all(const gs_sage3_bwd *p, int64_t n_pairs, int
     ra.n_seg = n;
 
     hipStream_t s = (hipStream_t)stream;
+    // rows of 4 * U children per request: all of a subtree's where that fits two sets of rows in the registers
+    const int u_rows = n1 <= 12 ? 3 : n1 <= 16 ? 4 : 8;
+    const bool mask = a.mask_hop2[0] != nullptr;
+#define GS_B3K(f, u, m)                                                                                             \
+    if (F == f && u_rows == u && mask == m) {                                                                       \
+        k2 = reinterpret_cast<const void *>(sage3_bwd_subtrees_kernel<f, u, m>);                                    \
+        launch2 = [](const Bwd3Args &b, long long nb, size_t lds, hipStream_t st, int row0) {                       \
+            hipLaunchKernelGGL((sage3_bwd_subtrees_kernel<f, u, m>), dim3((unsigned)nb), dim3(kThreads), lds, st, b, row0); \
+        };                                                                                                          \
+    }
 #define GS_B3(f)                                                                                                    \
     if (F == f) {                                                                                                   \
         const size_t lds = bwd3_lds<f>();                                                                           \
         const void *k1 = head ? reinterpret_cast<const void *>(sage3_bwd_seeds_kernel<f, true>)                     \
                               : reinterpret_cast<const void *>(sage3_bwd_seeds_kernel<f, false>);                   \
-        const void *k2 = n1 <= 16 ? reinterpret_cast<const void *>(sage3_bwd_subtrees_kernel<f, 4>)                 \
-                                  : reinterpret_cast<const void *>(sage3_bwd_subtrees_kernel<f, 8>);                \
+        const void *k2 = nullptr;                                                                                   \
+        void (*launch2)(const Bwd3Args &, long long, size_t, hipStream_t, int) = nullptr;                           \
+        GS_B3K(f, 3, true) GS_B3K(f, 3, false) GS_B3K(f, 4, true) GS_B3K(f, 4, false) GS_B3K(f, 8, true) GS_B3K(f, 8, false) \
         hipError_t attr = gs::raise_lds_limit(k1, (int)lds);                                                        \
         if (attr == hipSuccess) attr = gs::raise_lds_limit(k2, (int)lds);                                           \
         if (attr != hipSuccess) return gs::fail(GS_ELAUNCH, "%s: %s", who, hipGetErrorString(attr));                \
         if (head) hipLaunchKernelGGL((sage3_bwd_seeds_kernel<f, true>), dim3((unsigned)bt), dim3(kThreads), lds, s, a);   \
         else hipLaunchKernelGGL((sage3_bwd_seeds_kernel<f, false>), dim3((unsigned)bt), dim3(kThreads), lds, s, a); \
         if (int rc = gs::check_launch("gs_sage3_backward_all (seeds)")) return rc;                                  \
-        if (n1 <= 16) hipLaunchKernelGGL((sage3_bwd_subtrees_kernel<f, 4>), dim3((unsigned)bs), dim3(kThreads), lds, s, a, (int)bt); \
-        else hipLaunchKernelGGL((sage3_bwd_subtrees_kernel<f, 8>), dim3((unsigned)bs), dim3(kThreads), lds, s, a, (int)bt); \
+        launch2(a, bs, lds, s, (int)bt);                                                                            \
         if (int rc = gs::check_launch("gs_sage3_backward_all (subtrees)")) return rc;                               \
     }
     GS_B3(32) GS_B3(64)
 #undef GS_B3
+#undef GS_B3K
     return launch_bwd_reduce(ra, a.slab, (int)(bt + bs), row_floats, s, "gs_sage3_backward_all (reduce)");
 }
