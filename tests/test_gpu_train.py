@@ -954,3 +954,53 @@ def test_weight_gradients_with_own_rows_read_by_id_equal_the_gathered_form(cuda,
     with pytest.raises(Exception):
         bad = [dict(p, x_self=torch.zeros(10, 24, device=cuda), x_mean=torch.zeros(m, 24, device=cuda)) for p in by_id]
         kernels.WgradPairCall(bad, act)
+
+
+@pytest.mark.parametrize('ns,f,b', [([5, 3, 2], 64, 48), ([3, 2, 2], 32, 45), ([25, 10, 5], 64, 24)])
+def test_saving_subtree_forward_leaves_the_rows_of_the_layered_forward(cuda, ns, f, b):
+    """What the two-launch training forward (subtree kernel + seeds kernel, saving forms) leaves for the backward pass
+    against the layer-by-layer forward on the same draws: ids exact, means and outputs to rounding, the hop-2 mask words
+    against the sign of the layered outputs."""
+    from graphsage_amd.train import LinkHead
+    g, links, _ = _toy(5, fu=f, fi=f)
+    n0, n1, _ = ns
+    lk = np.asarray(links[:b])
+    seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+    walks = torch.arange(2 * b, dtype=torch.int64, device=cuda) + 1000
+    engines = []
+    for subtree in (True, False):
+        gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+        model = ga.GraphSAGE([32, 32, 32], gen, seed=11)
+        model.build()
+        tr = Trainer(model, head=LinkHead(32, cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
+        e = tr.engine
+        assert e.subtree_train
+        e.subtree_train = subtree
+        emb = e.forward_train(seeds, walks, rng_seed=21)
+        torch.cuda.synchronize()
+        engines.append((tr, e, [x.clone() for x in emb]))
+    (_, sub, emb_s), (_, lay, emb_l) = engines
+    close = lambda x, y, what: (float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max()))) or pytest.fail(what)
+    for x, y in zip(emb_s, emb_l):
+        close(x, y, 'embeddings')
+    r1, r2 = b * (1 + n0), b * (1 + n0 + n0 * n1)
+    st = sub._sub_train
+    # the drawn ids: hops 1 and 2 as the sampler lays them out (user-rooted walks first)
+    assert torch.equal(st['hop1'], lay.hops[0].reshape(-1)) and torch.equal(st['hop2'], lay.hops[1].reshape(-1))
+    for t, first in (('user', False), ('item', True)):               # hop-1 nodes of type t: items hang below the user seeds (first half)
+        half = slice(0, b * n0) if first else slice(b * n0, 2 * b * n0)
+        close(st['h0'][half], lay.h[0][t][b:r1], 'h0 of hop-1 nodes, ' + t)
+        close(st['h1'][half], lay.h[1][t][b:r1], 'h1 of hop-1 nodes, ' + t)
+    for t in ('user', 'item'):
+        close(sub.x_mean[0][t][:r2], lay.x_mean[0][t][:r2], 'layer-0 neighbor means, ' + t)
+        close(sub.x_mean[1][t][:r1], lay.x_mean[1][t][:r1], 'layer-1 neighbor means, ' + t)
+        close(sub.x_mean[2][t][:b], lay.x_mean[2][t][:b], 'layer-2 neighbor means, ' + t)
+        close(sub.h[0][t][:b], lay.h[0][t][:b], 'h0 of seeds, ' + t)
+        close(sub.h[1][t][:b], lay.h[1][t][:b], 'h1 of seeds, ' + t)
+        close(sub.z[t], lay.z[t], 'z, ' + t)
+        words = st['mask'][t].cpu().numpy().view(np.uint32)
+        bits = ((words[:, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)
+        rows = lay.h[0][t][r1:r2].cpu().numpy()
+        wrong = bits != (rows > 0)
+        assert not (wrong & (rows > 1e-6)).any()                        # (an output that rounds to zero on one route may be a tiny positive on the other)
+        assert wrong.mean() < 1e-3
