@@ -64,6 +64,6 @@ extern "C" int gs_timer_destroy(void *timer) {
     return GS_OK;
 }
 
-extern "C" int gs_version(void) { return 6; }
+extern "C" int gs_version(void) { return 7; }
 
 extern "C" const char *gs_last_error(void) { return gs::error_buffer(); }
