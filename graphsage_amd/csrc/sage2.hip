@@ -145,18 +145,18 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     const uint32_t *tape0 = tape;
     const uint32_t *tape1 = tape ? tape + n0 : nullptr;
     wave_lds_fence();                        // the previous walk's readers of s_ids / A / H1t are done
+    int32_t my_hop1 = -1;                    // lane t: hop-1 head t (SAVE: stored later, see below)
     {
         const uint32_t deg = (uint32_t)(rb - ra);
         if (root >= 0 && deg == 0 && lane == 0) atomicMax(&a.err[0], root + 1);
         const bool live = root >= 0 && deg != 0;
-        for (int t = lane; t < n0; t += 64) {
+        for (int t = lane; t < n0; t += 64) {                // (n0 <= 64: one trip)
             const uint32_t rr = tape ? tape0[t] : gs::philox4x32_10_x(wlo, whi, 0u, (uint32_t)t, a.key0, a.key1);
             int32_t v = a.indices[live ? ra + (int64_t)__umulhi(rr, deg) : 0];
             if (!live) v = -1;
             hop1[t] = v;
+            my_hop1 = v;
             if (a.out_hop1) a.out_hop1[(size_t)w * n0 + t] = v;
-            if (SAVE && a.sv_self_ids[1 - side])              // row of hop-1 head t in the other type's tables
-                a.sv_self_ids[1 - side][a.n_pairs + (w - (side ? a.n_pairs : 0)) * n0 + t] = v;
         }
     }
     wave_lds_fence();
@@ -278,6 +278,11 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             float *dst = a.sv_x_mean[1 - side] + (size_t)(sv_h1row + j0) * FT;
             for (int i = lane; i < np * FTV; i += 64)
                 stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(A + (i / FTV) * LDA + 4 * (i % FTV)));
+            // The heads' node ids (their rows in the other type's tables) go out here and not where they are drawn: the
+            // wait for a load counts the stores issued before it too, and the draws of hop 2 wait right behind those of
+            // hop 1, while nothing waits for memory until the matrix products below are through.
+            if (j0 == 0 && a.sv_self_ids[1 - side] && lane < n0)
+                a.sv_self_ids[1 - side][sv_h1row + lane] = my_hop1;
         }
         f32x4 acc_s[NT1], acc_n[NT1];
 #pragma unroll
@@ -410,22 +415,22 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
                 stream_store(a.sv_h1[side] + (size_t)pair * H1 + 4 * lane, *reinterpret_cast<const float4 *>(H1t + 4 * lane));
             if (a.sv_h1_mask[1 - side]) {
                 // the hop-1 heads' activations are read back only for their relu mask: one bit per element,
-                // 64 / H1 rows per ballot (lane = row * H1 + column: the ballot's words are the rows' words)
+                // 64 / H1 rows per ballot (lane = row * H1 + column: the ballot's words are the rows' words).  Lane t
+                // keeps the two words of ballot t, and all go out in two store instructions (one lane storing word
+                // after word costs a store and its acknowledgement per word, which the next walk's first loads wait for).
                 constexpr int RPB = 64 / H1;
                 uint32_t *mw = a.sv_h1_mask[1 - side] + (size_t)pair * n0 * (H1 / 32);
-                for (int j0 = 0; j0 < n0; j0 += RPB) {
-                    const int j = j0 + lane / H1;
+                const int n_ballots = (n0 + RPB - 1) / RPB;  // (<= 64: n0 <= 64)
+                uint32_t w_lo = 0, w_hi = 0;
+                for (int t = 0; t < n_ballots; ++t) {
+                    const int j = t * RPB + lane / H1;
                     const bool on = j < n0 && H1t[(1 + min(j, n0 - 1)) * LDH + lane % H1] > 0.f;
                     const unsigned long long bits = __ballot(on);
-                    if (lane == 0) {
-                        if (H1 == 32) {
-                            mw[j0] = (uint32_t)bits;
-                            if (j0 + 1 < n0) mw[j0 + 1] = (uint32_t)(bits >> 32);
-                        } else {
-                            mw[2 * j0] = (uint32_t)bits;
-                            mw[2 * j0 + 1] = (uint32_t)(bits >> 32);
-                        }
-                    }
+                    if (lane == t) { w_lo = (uint32_t)bits; w_hi = (uint32_t)(bits >> 32); }
+                }
+                if (lane < n_ballots) {
+                    mw[2 * lane] = w_lo;
+                    if (H1 == 64 || 2 * lane + 1 < n0) mw[2 * lane + 1] = w_hi;
                 }
             } else {
                 float *dst = a.sv_h1[1 - side] + (size_t)sv_h1row * H1;
