@@ -222,3 +222,34 @@ def test_wide_layer_kernel_reads_a_table_beyond_4_gib(cuda):
     row = np.concatenate([xs @ ws.cpu().numpy().astype(np.float64), xn @ wn.cpu().numpy().astype(np.float64)])
     row = np.maximum(row + bias.cpu().numpy(), 0.0)
     assert np.abs(got[-1].cpu().numpy() - row).max() <= 2e-5 * max(1.0, np.abs(row).max())
+
+
+def test_three_hop_training_step_at_full_batch_two_forward_routes_agree(big, cuda):
+    """B = 4096, fan-outs [25, 10, 5] on the benchmark graph: a training step with the forward pass as the saving
+    subtree kernel + seeds kernel against the same step on the layer-by-layer forward (both under the two-kernel
+    backward pass): same loss and gradients up to the order of the sums; the step repeats its bits."""
+    from graphsage_amd.train import LinkHead, Trainer
+    g = big['g']
+    fan = [25, 10, 5]
+    seeds = torch.cat([big['hu'][:B], big['hi'][:B]]).contiguous()
+    walks = torch.arange(2 * B, dtype=torch.int64, device=cuda) + (1 << 35)
+    targets = (torch.arange(B, device=cuda) % 2).float()
+    out = []
+    for subtree in (True, False, True):
+        gen = ga.GraphSAGEGenerator(g, B, fan, head_node_types=['user', 'item'], seed=1)
+        model = ga.GraphSAGE([32, 32, 32], gen, seed=11).build()
+        tr = Trainer(model, head=LinkHead(32, cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=B)
+        assert tr.engine.subtree_train and tr.engine.fused_backward3
+        tr.engine.subtree_train = subtree
+        loss, pred = tr.step_device(seeds, targets, walks, rng_seed=SEED)
+        assert tr.engine.err_flag.tolist() == [0, 0]
+        out.append((float(loss), tr.bucket.flat.clone(), pred.clone(), tr.opt.p_flat.clone()))
+        del tr, model, gen
+        torch.cuda.empty_cache()
+    assert np.isfinite(out[0][0]) and torch.isfinite(out[0][1]).all()
+    scale = float(out[1][1].abs().max())
+    assert scale > 0
+    assert abs(out[0][0] - out[1][0]) <= 1e-6 * max(1.0, abs(out[1][0]))
+    assert float((out[0][2] - out[1][2]).abs().max()) <= 2e-6
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 2e-5 * scale
+    assert out[0][0] == out[2][0] and torch.equal(out[0][1], out[2][1]) and torch.equal(out[0][3], out[2][3])
