@@ -51,7 +51,11 @@ constexpr int heads_in_flight(int hh1) { return hh1 >= 32 ? 2 : 1; }
 constexpr int sub_waves(int hh1) { return hh1 >= 32 ? 8 : 12; }
 // The saving form (training) likewise: 31 spilled vector registers at sixteen waves, none at twelve (training step
 // 194 -> 189 us on the default workload); the plain walk kernel has none at sixteen and is faster there.
-constexpr int block_waves(int hh1, bool save, bool sub, int fmax) { return (save || sub) ? sub_waves(hh1) : max_waves(hh1, fmax); }
+constexpr int block_waves(int hh1, bool save, bool sub, int fmax, bool drop = false) {
+    if (sub) return sub_waves(hh1);
+    if (save) return (hh1 < 32 && fmax <= 64 && !drop) ? max_waves(hh1, fmax) : sub_waves(hh1);
+    return max_waves(hh1, fmax);
+}
 constexpr int kUnroll = 10;              // row loads in flight per lane in the mean phase
 constexpr int kChunks = 4;               // 64-slot chunks sampled per pass
 constexpr int kGroup = 8;                // subtree mode: roots a wavefront takes together
@@ -133,6 +137,11 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     int32_t *hop1 = s_ids, *hop2 = s_ids + n0;
     int wl = lane;
     asm volatile("" : "+v"(wl));            // keeps the weight-fragment reads inside the walk loop
+    // The lane number as the saving stores see it: a value of this walk, so that the per-lane part of their addresses
+    // is computed where a store is made.  From `lane` itself the compiler computes every table's per-lane address once
+    // per kernel and keeps the fourteen of them (two registers each) alive through the gathers.
+    int sl = lane;
+    asm volatile("" : "+v"(sl));
 
     // ---- sampling ---------------------------------------------------------------
     // the caller maps out-of-range roots to -1
@@ -276,13 +285,13 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         wave_lds_fence();
         if (SAVE) {                          // the tile of neighbor means, out of LDS: np consecutive table rows
             float *dst = a.sv_x_mean[1 - side] + (size_t)(sv_h1row + j0) * FT;
-            for (int i = lane; i < np * FTV; i += 64)
+            for (int i = sl; i < np * FTV; i += 64)
                 stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(A + (i / FTV) * LDA + 4 * (i % FTV)));
             // The heads' node ids (their rows in the other type's tables) go out here and not where they are drawn: the
             // wait for a load counts the stores issued before it too, and the draws of hop 2 wait right behind those of
             // hop 1, while nothing waits for memory until the matrix products below are through.
-            if (j0 == 0 && a.sv_self_ids[1 - side] && lane < n0)
-                a.sv_self_ids[1 - side][sv_h1row + lane] = my_hop1;
+            if (j0 == 0 && a.sv_self_ids[1 - side] && sl < n0)
+                a.sv_self_ids[1 - side][sv_h1row + sl] = my_hop1;
         }
         f32x4 acc_s[NT1], acc_n[NT1];
 #pragma unroll
@@ -343,10 +352,10 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
         if (lane < FOV) {
             const float4 mean = make_float4(rootsum.x / d0, rootsum.y / d0, rootsum.z / d0, rootsum.w / d0);
             *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
-            if (SAVE) stream_store(a.sv_x_mean[side] + (size_t)pair * FO + 4 * lane, mean);
+            if (SAVE) stream_store(a.sv_x_mean[side] + (size_t)pair * FO + 4 * sl, mean);
         }
-        if (SAVE && a.sv_x_self[side] && lane < FTV) stream_store(a.sv_x_self[side] + (size_t)pair * FT + 4 * lane, own_root);
-        if (SAVE && a.sv_self_ids[side] && lane == 0) a.sv_self_ids[side][pair] = root;
+        if (SAVE && a.sv_x_self[side] && sl < FTV) stream_store(a.sv_x_self[side] + (size_t)pair * FT + 4 * sl, own_root);
+        if (SAVE && a.sv_self_ids[side] && sl == 0) a.sv_self_ids[side][pair] = root;
         wave_lds_fence();
         f32x4 acc_s[NT1], acc_n[NT1];
 #pragma unroll
@@ -406,13 +415,13 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             if (lane < H1V) {
                 const float4 mean = make_float4(s.x / d0, s.y / d0, s.z / d0, s.w / d0);
                 *reinterpret_cast<float4 *>(A + 4 * lane) = mean;
-                if (SAVE) stream_store(a.sv_x_mean1[side] + (size_t)pair * H1 + 4 * lane, mean);
+                if (SAVE) stream_store(a.sv_x_mean1[side] + (size_t)pair * H1 + 4 * sl, mean);
             }
         }
         if (SAVE) {
             // layer-0 activations: the root's row, then the hop-1 heads' rows as one contiguous block (LDH == H1)
-            if (lane < H1V)
-                stream_store(a.sv_h1[side] + (size_t)pair * H1 + 4 * lane, *reinterpret_cast<const float4 *>(H1t + 4 * lane));
+            if (sl < H1V)
+                stream_store(a.sv_h1[side] + (size_t)pair * H1 + 4 * sl, *reinterpret_cast<const float4 *>(H1t + 4 * sl));
             if (a.sv_h1_mask[1 - side]) {
                 // the hop-1 heads' activations are read back only for their relu mask: one bit per element,
                 // 64 / H1 rows per ballot (lane = row * H1 + column: the ballot's words are the rows' words).  Lane t
@@ -428,13 +437,13 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
                     const unsigned long long bits = __ballot(on);
                     if (lane == t) { w_lo = (uint32_t)bits; w_hi = (uint32_t)(bits >> 32); }
                 }
-                if (lane < n_ballots) {
-                    mw[2 * lane] = w_lo;
-                    if (H1 == 64 || 2 * lane + 1 < n0) mw[2 * lane + 1] = w_hi;
+                if (sl < n_ballots) {
+                    mw[2 * sl] = w_lo;
+                    if (H1 == 64 || 2 * sl + 1 < n0) mw[2 * sl + 1] = w_hi;
                 }
             } else {
                 float *dst = a.sv_h1[1 - side] + (size_t)sv_h1row * H1;
-                for (int i = lane; i < n0 * H1V; i += 64)
+                for (int i = sl; i < n0 * H1V; i += 64)
                     stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(H1t + LDH + 4 * i));
             }
         }
@@ -456,9 +465,9 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
             ss += o[0][ct] * o[0][ct] + o[1][ct] * o[1][ct];
         }
         if (SAVE && q == 0) {
-            float *dz = a.sv_z[side] + (size_t)pair * H2;
+            float *dz = a.sv_z[side] + (size_t)pair * H2 + (sl & 15);
 #pragma unroll
-            for (int ct = 0; ct < NT2; ++ct) { dz[ct * 16 + r] = o[0][ct]; dz[HH2 + ct * 16 + r] = o[1][ct]; }
+            for (int ct = 0; ct < NT2; ++ct) { dz[ct * 16] = o[0][ct]; dz[HH2 + ct * 16] = o[1][ct]; }
         }
         if (a.normalize) {
 #pragma unroll
@@ -823,7 +832,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
 }
 
 template <int FU, int FI, int HH1, int HH2, bool BUF, bool SAVE, bool SUB, bool DROP = false>
-__global__ __launch_bounds__(block_waves(HH1, SAVE, SUB, FU > FI ? FU : FI) * 64)
+__global__ __launch_bounds__(block_waves(HH1, SAVE, SUB, FU > FI ? FU : FI, DROP) * 64)
 void sage2_kernel(const Sage2Args a) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     constexpr int H1 = S::H1, H2 = S::H2, LDA = S::LDA, LDH = S::LDH;
@@ -952,7 +961,7 @@ int launch_one(const Sage2Args &a, hipStream_t stream) {
     using S = Sage2Shape<FU, FI, HH1, HH2>;
     constexpr int roots = SUB ? kGroup : 0;
     constexpr bool summed = sum_rows(HH1, SAVE, SUB);
-    int waves = block_waves(HH1, SAVE, SUB, S::FMAX);                 // as many waves per CU as the LDS budget admits
+    int waves = block_waves(HH1, SAVE, SUB, S::FMAX, DROP);                 // as many waves per CU as the LDS budget admits
     while (waves > 4 && S::lds_bytes(a.n0, a.n1, waves, roots, summed) > kLdsMax) waves -= 2;
     const size_t lds = S::lds_bytes(a.n0, a.n1, waves, roots, summed);
     if (lds > kLdsMax) return gs::fail(GS_ELIMIT, "gs_sage2_forward: %zu B of LDS per block needed (limit %zu)", lds, kLdsMax);
