@@ -141,7 +141,7 @@ __device__ __forceinline__ void walk_body(const Sage2Args &a, long long w, int s
     // is computed where a store is made.  From `lane` itself the compiler computes every table's per-lane address once
     // per kernel and keeps the fourteen of them (two registers each) alive through the gathers.
     int sl = lane;
-    asm volatile("" : "+v"(sl));
+    if constexpr (SAVE) asm volatile("" : "+v"(sl));
 
     // ---- sampling ---------------------------------------------------------------
     // the caller maps out-of-range roots to -1
@@ -565,6 +565,11 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
     int32_t *hop1 = s_ids, *hop2 = s_ids + NH;
     int wl = lane;
     asm volatile("" : "+v"(wl));            // keeps the weight-fragment reads inside the group loop
+    // The lane number as the stores to memory see it.  In the saving form a value of this group, so that no table's
+    // per-lane address is computed once and kept through the gathers (fifteen spilled registers otherwise); the plain
+    // form has few stores and is 1.5 % faster without.
+    int sl = lane;
+    if constexpr (SAVE) asm volatile("" : "+v"(sl));
     // saving: the group's first root within its node type, and the heads that belong to roots that exist
     const long long sv_root0 = w0 - (side ? 0 : a.n_pairs);
     const int nh_valid = n_valid * n0;
@@ -587,7 +592,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
     // ---- sampling ---------------------------------------------------------------
     wave_lds_fence();                        // the previous group's readers of s_ids / A / H1t are done
     for (int t0 = 0; t0 < NH; t0 += 64) {    // (whole-wave trips: the shuffles below read lanes 0 .. G-1)
-        const int t = min(t0 + lane, NH - 1);
+        const int t = min(t0 + sl, NH - 1);
         const int g = t / n0, tl = t - g * n0;
         const int32_t rg = __shfl(rootv, g, 64);
         const int64_t ra = __shfl(rav, g, 64), rb = __shfl(rbv, g, 64);
@@ -600,7 +605,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
                                      : gs::philox4x32_10_x((unsigned)wk, (unsigned)(wk >> 32), 1u, slot, a.key0, a.key1);
         int32_t v = a.indices[live ? ra + (int64_t)__umulhi(rr, deg) : 0];
         if (!live) v = -1;
-        if (t0 + lane < NH) {
+        if (t0 + sl < NH) {
             hop1[t] = v;
             if (a.out_hop1 && g < n_valid) a.out_hop1[(size_t)(w0 + g) * n0 + tl] = v;
         }
@@ -637,7 +642,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
             }
 #pragma unroll
             for (int c = 0; c < kChunks; ++c) {
-                const int t = base + c * 64 + lane;
+                const int t = base + c * 64 + sl;
                 if (t < total) {
                     const int g = t / per_root, local = t - g * per_root;
                     hop2[t] = tabT.entry(v[c], offT, FT * 4);
@@ -676,7 +681,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
         const int nv = min(np, nh_valid - j0);                   // rows of this tile the saved tables have (may be < 1)
         if (SAVE) {                          // the tile of neighbor means, out of LDS: nv consecutive table rows
             float *dst = a.sv_x_mean[1 - side] + (size_t)(sv_root0 * n0 + j0) * FT;
-            for (int i = lane; i < nv * FTV; i += 64)
+            for (int i = sl; i < nv * FTV; i += 64)
                 stream_store(dst + 4 * i, *reinterpret_cast<const float4 *>(A + (i / FTV) * LDA + 4 * (i % FTV)));
         }
         f32x4 acc_s[NT1], acc_n[NT1];
@@ -725,10 +730,10 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
                 const unsigned long long bits = __ballot(A[(2 * t + (lane >> 5)) * LDA + (lane & 31)] > 0.f);
                 if (lane == t) { w_lo = (uint32_t)bits; w_hi = (uint32_t)(bits >> 32); }
             }
-            uint32_t *mw = a.sv_h1_mask[1 - side] + (size_t)(sv_root0 * n0 + j0) + 2 * lane;    // (8-byte aligned: kGroup and 16 are even)
-            if (lane < 8) {
-                if (2 * lane + 1 < nv) *reinterpret_cast<uint2 *>(mw) = make_uint2(w_lo, w_hi);
-                else if (2 * lane < nv) *mw = w_lo;
+            uint32_t *mw = a.sv_h1_mask[1 - side] + (size_t)(sv_root0 * n0 + j0) + 2 * sl;      // (8-byte aligned: kGroup and 16 are even)
+            if (sl < 8) {
+                if (2 * sl + 1 < nv) *reinterpret_cast<uint2 *>(mw) = make_uint2(w_lo, w_hi);
+                else if (2 * sl < nv) *mw = w_lo;
             }
         }
 #pragma unroll
@@ -751,7 +756,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
         const float d0 = (float)n0;
 #pragma unroll
         for (int k = 0; k < RS_N; ++k) {
-            const int idx = k * 64 + lane;
+            const int idx = k * 64 + sl;
             if (idx < G * FOV) {
                 const float4 mean = make_float4(rs[k].x / d0, rs[k].y / d0, rs[k].z / d0, rs[k].w / d0);
                 *reinterpret_cast<float4 *>(A + (idx / FOV) * LDA + 4 * (idx % FOV)) = mean;
@@ -791,7 +796,7 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
         const float d0 = (float)n0;
 #pragma unroll
         for (int k = 0; k < L1_N; ++k) {     // lane (g, c): column chunk c of the mean of root g's heads' activations
-            const int idx = k * 64 + lane;
+            const int idx = k * 64 + sl;
             if (idx < G * H1V) {
                 const int g = idx / H1V, c = idx % H1V;
                 const float4 mean = make_float4(hs[k].x / d0, hs[k].y / d0, hs[k].z / d0, hs[k].w / d0);
@@ -820,11 +825,11 @@ __device__ __forceinline__ void group_body(const Sage2Args &a, long long w0, int
         for (int i = 0; i < 4; ++i) {
             const int row = 4 * q + i;
             if (row < n_valid) {
-                float *dst = a.emb + (size_t)(w0 + row) * H2;
+                float *dst = a.emb + (size_t)(w0 + row) * H2 + (sl & 15);
 #pragma unroll
                 for (int ct = 0; ct < NT2; ++ct) {           // an inner layer: through relu, no normalisation
-                    dst[ct * 16 + r] = fmaxf(acc_s[ct][i] + b1_T[ct * 16 + r], 0.f);
-                    dst[HH2 + ct * 16 + r] = fmaxf(acc_n[ct][i] + b1_T[HH2 + ct * 16 + r], 0.f);
+                    dst[ct * 16] = fmaxf(acc_s[ct][i] + b1_T[ct * 16 + r], 0.f);
+                    dst[HH2 + ct * 16] = fmaxf(acc_n[ct][i] + b1_T[HH2 + ct * 16 + r], 0.f);
                 }
             }
         }
