@@ -122,6 +122,27 @@ void gather_mean_kernel(const float *__restrict__ feat, int64_t n_rows, int F, i
     }
 }
 
+// The same mean over dense groups (the children of parent p are rows p * NC .. p * NC + NC - 1, NC known at compile
+// time, 16-byte columns): a thread owns one 16-byte column of one parent, all NC loads are issued before the first add
+// and nothing is conditional, so the launch streams the table (the layers above the first of a wide model read their
+// neighbors this way).  The sum is formed in child order from zero and divided by NC as above: the same bits.
+template <int NC>
+__global__ __launch_bounds__(kThreads)
+void dense_mean_kernel(const float4 *__restrict__ feat, int fv, int64_t total, float4 *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t p = idx / fv;
+    const int c = (int)(idx - p * fv);
+    const float4 *src = feat + p * NC * fv + c;
+    float4 v[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) v[j] = src[(int64_t)j * fv];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) vadd(acc, v[j]);
+    out[idx] = vdiv(acc, (float)NC);
+}
+
 // Backward: one row group per parent broadcasts g/n to its children.
 template <int VEC>
 __global__ __launch_bounds__(kThreads)
@@ -226,6 +247,19 @@ int gather_reduce_fwd(const char *what, const float *feat, int64_t n_rows, int F
     if (!child_ids && n_parents * (int64_t)n_child > n_rows)
         return gs::fail(GS_EINVAL, "%s: dense groups need n_parents*n_child <= n_rows", what);
     const int vec = pick_vec(F, feat, out_mean);
+    hipStream_t s = (hipStream_t)stream;
+    if (!MAXOP && !child_ids && vec == 4 && (n_child == 5 || n_child == 10 || n_child == 25) &&
+        n_parents * (int64_t)(F / 4) <= ((int64_t)1 << 31) * kThreads) {
+        const int fv = F / 4;
+        const int64_t total = n_parents * fv;
+        const unsigned grid = (unsigned)((total + kThreads - 1) / kThreads);
+        const float4 *src = reinterpret_cast<const float4 *>(feat);
+        float4 *dst = reinterpret_cast<float4 *>(out_mean);
+        if (n_child == 5) gs::launch_timed(dense_mean_kernel<5>, dim3(grid), dim3(kThreads), 0, s, src, fv, total, dst);
+        else if (n_child == 10) gs::launch_timed(dense_mean_kernel<10>, dim3(grid), dim3(kThreads), 0, s, src, fv, total, dst);
+        else gs::launch_timed(dense_mean_kernel<25>, dim3(grid), dim3(kThreads), 0, s, src, fv, total, dst);
+        return gs::check_launch(what);
+    }
     const int lg = group_log2(F, vec);
     const int groups = kThreads >> lg;
     int tile = groups * 4;
@@ -234,7 +268,6 @@ int gather_reduce_fwd(const char *what, const float *feat, int64_t n_rows, int F
     if (stage && (int64_t)tile * n_child > kMaxTileIds) stage = 0;
     const size_t lds = stage ? (size_t)tile * n_child * sizeof(int32_t) : 0;
     const unsigned grid = grid_for(n_parents, tile);
-    hipStream_t s = (hipStream_t)stream;
     if (vec == 4) gs::launch_timed(gather_mean_kernel<4, MAXOP>, dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
     else if (vec == 2) gs::launch_timed(gather_mean_kernel<2, MAXOP>, dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);
     else gs::launch_timed(gather_mean_kernel<1, MAXOP>, dim3(grid), dim3(kThreads), lds, s, feat, n_rows, F, id_offset, child_ids, n_parents, n_child, out_mean, lg, tile, stage);

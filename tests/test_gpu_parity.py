@@ -275,7 +275,7 @@ def test_sampling_is_independent_of_batch_split_and_rank(golden, cuda):
 # ------------------------------------------------------------ gather-mean ----
 
 @pytest.mark.parametrize('f', [64, 24, 19, 30, 18, 256, 300, 1])
-@pytest.mark.parametrize('n_child', [10, 25, 1, 9])
+@pytest.mark.parametrize('n_child', [10, 25, 5, 1, 9])
 def test_gather_rows_and_gather_mean(cuda, f, n_child):
     rng = np.random.default_rng(f * 100 + n_child)
     n_rows, n_parents, off = 777, 133, 1000

@@ -27,15 +27,15 @@ from collections import defaultdict
 
 src, name = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ours = ('sage2_kernel', 'sage3_seeds_kernel', 'sage2_tail_bwd_kernel', 'sage2_bwd_all_kernel', 'sage3_bwd_seeds_kernel', 'sage3_bwd_subtrees_kernel', 'sage_bwd_reduce_kernel', 'stage_batch_kernel', 'sage_wide_kernel', 'l2norm_inplace_kernel', 'sage_fused_kernel', 'sample_kernel', 'gather_mean_kernel', 'gather_rows_kernel', 'rows_gemm_kernel',
+ours = ('sage2_kernel', 'sage3_seeds_kernel', 'sage2_tail_bwd_kernel', 'sage2_bwd_all_kernel', 'sage3_bwd_seeds_kernel', 'sage3_bwd_subtrees_kernel', 'sage_bwd_reduce_kernel', 'stage_batch_kernel', 'sage_wide_kernel', 'l2norm_inplace_kernel', 'sage_fused_kernel', 'sample_kernel', 'gather_mean_kernel', 'dense_mean_kernel', 'gather_rows_kernel', 'rows_gemm_kernel',
         'rows_gemm_big_kernel', 'wgrad_big_kernel', 'wgrad_kernel', 'wgrad_direct_kernel', 'wgrad_reduce_kernel', 'l2norm', 'link_head', 'adam_kernel', 'csr_',
         'group_max_bwd_kernel', 'head_')
 
 
-WIDE_READERS = ('sage2_kernel', 'sage3_seeds_kernel', 'sage_fused_kernel', 'sage_wide_kernel', 'gather_mean_kernel', 'gather_rows_kernel',
+WIDE_READERS = ('sage2_kernel', 'sage3_seeds_kernel', 'sage_fused_kernel', 'sage_wide_kernel', 'gather_mean_kernel', 'dense_mean_kernel', 'gather_rows_kernel',
                 'rows_gemm', 'wgrad', 'sage2_tail_bwd_kernel', 'sage2_bwd_all_kernel', 'sage3_bwd_seeds_kernel', 'sage3_bwd_subtrees_kernel', 'sage_bwd_reduce_kernel', 'link_head', 'adam_kernel', 'l2norm')
 SOURCE_OF = {'sage2_kernel': ('sage2.hip', 'sage_tile.h'), 'sage3_seeds_kernel': ('sage3_seeds.hip', 'sage_tile.h'), 'sage_fused_kernel': 'fused.hip', 'sage_wide_kernel': 'wide.hip',
-             'sample_kernel': 'sampler.hip', 'gather_mean_kernel': 'gather.hip'}
+             'sample_kernel': 'sampler.hip', 'gather_mean_kernel': 'gather.hip', 'dense_mean_kernel': 'gather.hip'}
 
 
 def fetch_factor(kernel):
