@@ -1005,3 +1005,26 @@ def test_saving_subtree_forward_leaves_the_rows_of_the_layered_forward(cuda, ns,
         wrong = bits != (rows > 0)
         assert not (wrong & (rows > 1e-6)).any()                        # (an output that rounds to zero on one route may be a tiny positive on the other)
         assert wrong.mean() < 1e-3
+
+
+@pytest.mark.parametrize('ns,f,b', [([5, 3, 2], 64, 48), ([25, 10, 5], 64, 21)])
+def test_three_hop_training_forward_gives_the_bits_of_the_inference_forward(cuda, ns, f, b):
+    """Saving what the backward pass reads changes nothing in what is computed: the two-launch forward of the training
+    plan (saving forms) and of the forward engine (plain forms) on the same draws, bit for bit."""
+    from graphsage_amd.engine import SageForwardEngine
+    from graphsage_amd.train import LinkHead
+    g, links, _ = _toy(5, fu=f, fi=f)
+    lk = np.asarray(links[:b])
+    seeds = torch.from_numpy(np.concatenate([lk[:, 0], lk[:, 1]]).astype(np.int32)).to(cuda)
+    walks = torch.arange(2 * b, dtype=torch.int64, device=cuda) + 77
+    gen = ga.GraphSAGEGenerator(g, b, ns, head_node_types=['user', 'item'], seed=3)
+    model = ga.GraphSAGE([32, 32, 32], gen, seed=11)
+    model.build()
+    tr = Trainer(model, head=LinkHead(32, cuda, seed=5), lr=1e-2, engine='plan', graph=g, batch_size=b)
+    assert tr.engine.subtree_train
+    train_emb = [x.clone() for x in tr.engine.forward_train(seeds, walks, rng_seed=4)]
+    fwd = SageForwardEngine(g, model, b)
+    assert fwd.subtree_kernel
+    infer_emb = fwd.forward(seeds, walks, rng_seed=4)
+    for x, y in zip(train_emb, infer_emb):
+        assert torch.equal(x, y)
