@@ -755,6 +755,54 @@ void wgrad_reduce_kernel(const ReduceSides sides, int n_chunks, int N) {
     }
 }
 
+// The same with four consecutive elements per thread and four interleaved chunk groups per block (N a multiple of
+// four, slabs 16-byte aligned): a block reads 1 KB of every chunk's row, eight loads in flight per thread.  Chunk c
+// goes to group c mod 4, the groups are added in order: reproducible like the form above (which keeps the shapes
+// this one does not take).
+__global__ __launch_bounds__(kThreads)
+void wgrad_reduce4_kernel(const ReduceSides sides, int n_chunks, int N) {
+    __shared__ f32x4 part[kThreads];
+    const ReduceSide &sd = sides.s[blockIdx.y];
+    const float *__restrict__ slab = sd.slab;
+    const int K = sd.K;
+    const int total = (K + 1) * N;
+    const int e = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int j = threadIdx.x >> 6;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (e < total) {
+        const float *src = slab + e;
+        int c = j;
+        for (; c + 28 < n_chunks; c += 32) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (int64_t)(c + 4 * u) * total);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; c < n_chunks; c += 4) acc += *reinterpret_cast<const f32x4 *>(src + (int64_t)c * total);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (j == 0 && e < total) {
+        const int l = threadIdx.x;
+        const f32x4 t = ((part[l] + part[64 + l]) + part[128 + l]) + part[192 + l];
+        if (e < K * N) { if (sd.gW) *reinterpret_cast<f32x4 *>(sd.gW + e) = t; }      // (K * N is a multiple of four: no straddling)
+        else if (sd.gbias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sd.gbias[e - K * N + i] = t[i];
+        }
+    }
+}
+
+inline void launch_wgrad_reduce(const ReduceSides &rs, int n_sides, int tot, int n_chunks, int N, hipStream_t s) {
+    bool vec = (N & 3) == 0;
+    for (int i = 0; i < n_sides; ++i)
+        vec = vec && (reinterpret_cast<uintptr_t>(rs.s[i].slab) & 15) == 0 &&
+              (!rs.s[i].gW || (reinterpret_cast<uintptr_t>(rs.s[i].gW) & 15) == 0);
+    if (vec) hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((tot + 255) / 256), n_sides), dim3(kThreads), 0, s, rs, n_chunks, N);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 15) / 16), n_sides), dim3(kThreads), 0, s, rs, n_chunks, N);
+}
+
 
 // ---- weight / bias gradient for narrow outputs, operands straight from global memory --------
 //
@@ -1148,7 +1196,7 @@ extern "C" int gs_sage_project_bwd(const float *x_self, int Fs, const float *x_m
         rs.s[0] = ReduceSide{slab0, g_W_self, g_bias, Fs};
         rs.s[1] = ReduceSide{slab1, g_W_neigh, g_bias ? g_bias + Hh : nullptr, Fn};
         const int tot = ((Fs > Fn ? Fs : Fn) + 1) * Hh;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 15) / 16), 2), dim3(kThreads), 0, s, rs, (int)nc, Hh);
+        launch_wgrad_reduce(rs, 2, tot, (int)nc, Hh, s);
         if (int rc = gs::check_launch("gs_sage_project_bwd (reduce)")) return rc;
     }
 
@@ -1243,7 +1291,7 @@ extern "C" int gs_sage_project_wgrad_pair(const gs_wgrad_problem *a, const gs_wg
         return gs::fail(GS_ELIMIT, "gs_sage_project_wgrad_pair: no kernel for Fs=%d Fn=%d H=%d", Fs, Fn, H);
     if (int rc = gs::check_launch("gs_sage_project_wgrad_pair (wgrad)")) return rc;
     const int tot = ((Fs > Fn ? Fs : Fn) + 1) * Hh;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 15) / 16), 4), dim3(kThreads), 0, s, rs, (int)nblocks, Hh);
+    launch_wgrad_reduce(rs, 4, tot, (int)nblocks, Hh, s);
     return gs::check_launch("gs_sage_project_wgrad_pair (reduce)");
 }
 

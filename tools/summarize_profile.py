@@ -28,7 +28,7 @@ from collections import defaultdict
 src, name = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ours = ('sage2_kernel', 'sage3_seeds_kernel', 'sage2_tail_bwd_kernel', 'sage2_bwd_all_kernel', 'sage3_bwd_seeds_kernel', 'sage3_bwd_subtrees_kernel', 'sage_bwd_reduce_kernel', 'stage_batch_kernel', 'sage_wide_kernel', 'l2norm_inplace_kernel', 'sage_fused_kernel', 'sample_kernel', 'gather_mean_kernel', 'dense_mean_kernel', 'gather_rows_kernel', 'rows_gemm_kernel',
-        'rows_gemm_big_kernel', 'wgrad_big_kernel', 'wgrad_kernel', 'wgrad_direct_kernel', 'wgrad_reduce_kernel', 'l2norm', 'link_head', 'adam_kernel', 'csr_',
+        'rows_gemm_big_kernel', 'wgrad_big_kernel', 'wgrad_kernel', 'wgrad_direct_kernel', 'wgrad_reduce_kernel', 'wgrad_reduce4_kernel', 'l2norm', 'link_head', 'adam_kernel', 'csr_',
         'group_max_bwd_kernel', 'head_')
 
 
